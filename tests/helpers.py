@@ -1,0 +1,86 @@
+"""Shared test helpers: synthetic generators and brute-force CTC."""
+import itertools
+
+import numpy as np
+
+
+def softmax0(x):
+    e = np.exp(x - x.max(axis=0, keepdims=True))
+    return e / e.sum(axis=0, keepdims=True)
+
+
+def time_trials_input():
+    """ctc/time_trials.py:13-25 (seed 33, A=40, U=125, T=1200, peaked)."""
+    np.random.seed(33)
+    A, U, T = 40, 125, 1200
+    seq = np.floor(np.random.rand(U) * A).astype(np.int32)
+    p = np.random.randn(A, T)
+    p[seq, np.arange(U)] = 3
+    p[0, U:] = 3
+    p = np.exp(p)
+    p = p / np.sum(p, axis=0)
+    return p, seq
+
+
+def mid_input(T, A, U, seed):
+    rs = np.random.RandomState(seed)
+    logits = rs.randn(A, T)
+    seq = rs.randint(1, A, size=U).astype(np.int32)
+    return logits, seq
+
+
+def collapse(path, blank=0):
+    out = []
+    prev = None
+    for k in path:
+        if k != prev and k != blank:
+            out.append(k)
+        prev = k
+    return out
+
+
+def brute_force_ctc(y, seq, blank=0):
+    """-ln sum over all A^T frame labellings that collapse to seq (tiny cases only).
+    Only meaningful when no label equals the blank id."""
+    A, T = y.shape
+    total = 0.0
+    target = list(seq)
+    for path in itertools.product(range(A), repeat=T):
+        if collapse(path, blank) == target:
+            p = 1.0
+            for t, k in enumerate(path):
+                p *= y[k, t]
+            total += p
+    return -np.log(total)
+
+
+def fd_grad_logits(fn, logits, seq, eps=1e-5):
+    """central finite difference of cost wrt logits; fn(logits, seq) -> cost"""
+    g = np.zeros_like(logits)
+    for k in range(logits.shape[0]):
+        for t in range(logits.shape[1]):
+            lp = logits.copy()
+            lm = logits.copy()
+            lp[k, t] += eps
+            lm[k, t] -= eps
+            g[k, t] = (fn(lp, seq) - fn(lm, seq)) / (2 * eps)
+    return g
+
+
+def load_net(npz, prefix=""):
+    """fixture -> (params dict for oracle.brnn, grads dict, dims, data, labels, cost)"""
+    n = int(npz[prefix + "n"])
+    D, A, H, NL, TL, T = [int(v) for v in npz[prefix + "dims"]]
+    W = [npz[prefix + "W%d" % i] for i in range(NL + 1)]
+    b = [npz[prefix + "b%d" % i] for i in range(NL + 1)]
+    dW = [npz[prefix + "dW%d" % i] for i in range(NL + 1)]
+    db = [npz[prefix + "db%d" % i] for i in range(NL + 1)]
+    params = {"W": W, "b": b, "Wf": None, "Wb": None}
+    grads = {"W": dW, "b": db, "Wf": None, "Wb": None}
+    if n == NL + 3:
+        params["Wf"] = npz[prefix + "W%d" % (NL + 1)]
+        params["Wb"] = npz[prefix + "W%d" % (NL + 2)]
+        grads["Wf"] = npz[prefix + "dW%d" % (NL + 1)]
+        grads["Wb"] = npz[prefix + "dW%d" % (NL + 2)]
+    return (params, grads, (D, A, H, NL, TL, T), npz[prefix + "data"], npz[prefix + "labels"],
+            float(npz[prefix + "cost"]))
