@@ -1,0 +1,222 @@
+/*
+ * sctc.h -- C ABI of libsctc_hip.so: the MI355X (gfx950) drop-in for the
+ * per-utterance training hot path of amaas/stanford-ctc.
+ *
+ * Every entry point replaces one interface of the reference (cited per function,
+ * paths relative to the reference root).  The reference is Python over (a) a
+ * Cython extension `ctc_fast` and (b) the cudamat CUDA library; a maintainer binds
+ * this header with ctypes (INTEGRATION.md shows the stubs; the host-side mirror in
+ * stanford-ctc_amd/ is exactly that binding).
+ *
+ * Conventions
+ *   - plain C types only; `void* stream` is a hipStream_t (NULL = default stream).
+ *   - "dev" pointers are HIP device pointers, "host" pointers ordinary memory.
+ *   - the library never allocates device memory: the caller hands in parameter,
+ *     gradient and workspace buffers (sizes come from the *_query functions).
+ *   - return 0 (SCTC_OK) on success, < 0 on error (sctc_last_error() has the text).
+ *     Numerical failure of an utterance (the reference's `skip`, ctc_fast.pyx:147-149)
+ *     is reported through skip flags, never through the return code.
+ *   - matrices: the reference stores (features x frames) column-major, i.e. one
+ *     frame = `features` consecutive floats.  Here that is row-major [frames][ld].
+ */
+#ifndef SCTC_H_
+#define SCTC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCTC_ABI_VERSION 1
+
+#define SCTC_OK 0
+#define SCTC_ERR_ARG (-1)       /* bad argument (the reference raises ValueError/AssertionError) */
+#define SCTC_ERR_HIP (-2)       /* HIP runtime error */
+#define SCTC_ERR_WORKSPACE (-3) /* workspace too small */
+#define SCTC_ERR_TIMEOUT (-4)   /* persistent-kernel grid barrier timed out (device not exclusively ours) */
+#define SCTC_ERR_STATE (-5)
+
+#define SCTC_F32 0
+#define SCTC_F64 1
+
+/* ---- library ---------------------------------------------------------- */
+
+int sctc_abi_version(void);
+const char* sctc_last_error(void);
+/* cm.cuda_set_device(n), runNNet.py:117-120 */
+int sctc_set_device(int device);
+/* compute units / LDS per CU / total memory of the current device (any may be NULL) */
+int sctc_device_info(int* compute_units, int* lds_bytes_per_cu, int64_t* total_mem_bytes,
+                     char* name, int name_len);
+/* runs the cross-lane / MFMA fragment-layout probes; 0 = all as expected, else a bitmask */
+int sctc_selftest(void* stream);
+
+/* ---- CTC: ctc_fast/ctc-loss/ctc_fast.pyx ------------------------------- */
+
+/* Layout of a batch of utterances over the rows of `probs`/`grad`:
+ *   rowbase_dev == NULL : utterance b owns rows frame_off[b] .. frame_off[b]+T_b[b]-1
+ *                         (frame t = row frame_off[b]+t) -- the reference's (A,T) F-order
+ *                         array is exactly one such block with ld == A;
+ *   rowbase_dev != NULL : packed time-major minibatch, frame t of utterance b is row
+ *                         rowbase_dev[t] + frame_off[b]  (utterances sorted by length,
+ *                         frame_off[b] = rank of b; used by the BRNN engine).            */
+typedef struct sctc_ctc_batch {
+    int32_t B;                 /* utterances */
+    int32_t A;                 /* alphabet size incl. blank (params.shape[0], ctc_fast.pyx:24) */
+    int32_t blank;             /* blank id (ctc_fast.pyx:14) */
+    int32_t dtype;             /* SCTC_F32 | SCTC_F64: type of probs, grad and the lattices */
+    int64_t ld;                /* row stride of probs/grad in elements (>= A) */
+    const int32_t* T_b;        /* host [B]  frames per utterance  (params.shape[1]) */
+    const int32_t* U_b;        /* host [B]  labels per utterance  (seq.shape[0]), >= 1 */
+    const int64_t* frame_off;  /* host [B]  see above */
+    const int32_t* labels;     /* host, concatenated label ids (seq) */
+    const int64_t* label_off;  /* host [B]  first label of utterance b in `labels` */
+    const int32_t* rowbase_dev;/* device [max T] or NULL */
+} sctc_ctc_batch;
+
+/* bytes of device workspace sctc_ctc_loss_batch needs for this batch */
+size_t sctc_ctc_workspace_bytes(const sctc_ctc_batch* batch);
+
+/* ctc_loss(params, seq, blank) of ctc_fast.pyx:13-152 for B utterances at once.
+ *   probs_dev : softmax outputs (the reference's `params`), rows as described above
+ *   grad_dev  : d cost / d (pre-softmax activations), same layout as probs (ctc_fast.pyx:138-145);
+ *               zeros for utterances with skip != 0
+ *   cost_dev  : device double[B], -llForward (ctc_fast.pyx:152); +inf when T is too short
+ *               for the label sequence (empty band, log(0))
+ *   skip_dev  : device int32[B], 1 where the reference takes its except-branch
+ *               (a frame normaliser == 0: infeasible alignment / zero-probability label) */
+int sctc_ctc_loss_batch(const sctc_ctc_batch* batch, const void* probs_dev, void* grad_dev,
+                        double* cost_dev, int32_t* skip_dev, void* workspace_dev,
+                        size_t workspace_bytes, void* stream);
+
+/* brnnet.py:161-168 softmax over the alphabet for every frame (row):
+ * subtract the row max, exp, scale by 1/sum.  In place allowed. f32 only. */
+int sctc_softmax_rows(const float* logits_dev, float* probs_dev, int64_t rows, int32_t A,
+                      int64_t ld, void* stream);
+
+/* decode_best_path argmax stage (ctc_fast.pyx:165): per-row argmax over A, first maximum wins */
+int sctc_argmax_rows(const void* probs_dev, int32_t dtype, int32_t* best_dev, int64_t rows,
+                     int32_t A, int64_t ld, void* stream);
+
+/* ---- BRNN: ctc_fast/nnets/brnnet.py NNet ------------------------------- */
+
+typedef struct sctc_brnn_config {
+    int32_t input_dim;       /* inputDim   brnnet.py:10 */
+    int32_t output_dim;      /* outputDim  (alphabet incl. blank) */
+    int32_t layer_size;      /* layerSize  */
+    int32_t num_layers;      /* numLayers  */
+    int32_t temporal_layer;  /* temporalLayer; <=0 or >=numLayers means none (brnnet.py:27-30) */
+    int32_t max_frames;      /* capacity in frames summed over the minibatch (maxBatch for B=1) */
+    int32_t max_utts;        /* capacity in utterances per call (1 = reference semantics) */
+    float max_act;           /* maxAct = 20.0 (brnnet.py:32); <= 0 disables the ceiling (rnnetcpu.py) */
+    float reg;               /* L2 coefficient (brnnet.py:22) */
+    int32_t train;           /* 0: forward-only model (train=False) */
+} sctc_brnn_config;
+
+/* One parameter tensor of `stack` (brnnet.py:58-59,71-72): order
+ * [W1,b1] ... [W_{NL+1},b_{NL+1}] [Wf] [Wb]; stored row-major [rows][ld] inside the
+ * flat parameter buffer (ld = rows/cols rounded up, zero padded). */
+typedef struct sctc_tensor_info {
+    int64_t offset;  /* element offset in the flat params / grads buffers */
+    int32_t rows, cols, ld, kind; /* kind: 0 weight, 1 bias (cols == 1, ld == 1), 2 recurrent */
+} sctc_tensor_info;
+
+typedef struct sctc_brnn_sizes {
+    int64_t param_elems;      /* floats in the flat (padded) parameter buffer */
+    int64_t param_count;      /* unpadded count == NNet.paramCount() minus the dummy biases */
+    size_t workspace_bytes;   /* device workspace for activations, deltas, CTC lattices */
+    int32_t n_tensors;        /* 2*(NL+1) (+2 when there is a temporal layer) */
+} sctc_brnn_sizes;
+
+typedef struct sctc_brnn* sctc_brnn_t;
+
+int sctc_brnn_query(const sctc_brnn_config* cfg, sctc_brnn_sizes* out);
+/* NNet.__init__/initParams buffers (brnnet.py:10-86).  params/grads: device float[param_elems]
+ * owned by the caller for the lifetime of the handle (grads may be NULL when !train). */
+int sctc_brnn_create(const sctc_brnn_config* cfg, float* params_dev, float* grads_dev,
+                     void* workspace_dev, size_t workspace_bytes, sctc_brnn_t* out);
+int sctc_brnn_destroy(sctc_brnn_t h);
+int sctc_brnn_tensor_info(sctc_brnn_t h, int32_t index, sctc_tensor_info* out);
+
+/* Minibatch descriptor.  feats_dev: float [sum T][input_dim], utterances
+ * concatenated in caller order, each one the reference's (inputDim,T) F-order array. */
+typedef struct sctc_minibatch {
+    int32_t B;
+    const int32_t* T_b;       /* host [B] */
+    const float* feats_dev;
+    const int32_t* labels;    /* host concatenated (NULL for forward only) */
+    const int32_t* U_b;       /* host [B] */
+} sctc_minibatch;
+
+#define SCTC_FLAG_SYNC_SKIP 1   /* reference B=1 semantics: look at `skip` on the host before
+                                   the backward pass; if every utterance is skipped, return
+                                   with the gradients untouched (brnnet.py:185-186) */
+#define SCTC_FLAG_ACCUMULATE 2  /* add into grads instead of overwriting */
+
+/* NNet.costAndGrad(data, labels) (brnnet.py:117-249) for a minibatch: forward,
+ * softmax + CTC, backward.  Gradients are SUMMED over utterances (and frames) into
+ * grads_dev; skipped utterances contribute zero.
+ *   cost_host/skip_host [B] (optional, forces a stream sync), caller order;
+ *   costs include nothing of the L2 term: *regcost_host (optional) receives
+ *   sum (reg/2)*||w||^2 over all weight tensors (brnnet.py:178-183).                     */
+int sctc_brnn_cost_and_grad(sctc_brnn_t h, const sctc_minibatch* mb, int32_t flags,
+                            double* cost_host, int32_t* skip_host, double* regcost_host,
+                            void* stream);
+/* same, results stay on the device (no host sync): cost_dev double[B], skip_dev int32[B] */
+int sctc_brnn_cost_and_grad_async(sctc_brnn_t h, const sctc_minibatch* mb, int32_t flags,
+                                  double* cost_dev, int32_t* skip_dev, void* stream);
+
+/* NNet(train=False).costAndGrad(data) (brnnet.py:171-173): probs_dev float [sum T][output_dim],
+ * caller order, each utterance the reference's (outputDim,T) F-order probs */
+int sctc_brnn_forward(sctc_brnn_t h, const sctc_minibatch* mb, float* probs_dev, void* stream);
+
+/* rocprof-free timing hooks: seconds spent in the phases of the last call, measured
+ * with hipEvents on `stream` when enabled (adds syncs; for bench.py's roofline leg) */
+#define SCTC_PHASE_FWD_GEMM 0
+#define SCTC_PHASE_FWD_REC 1
+#define SCTC_PHASE_CTC 2
+#define SCTC_PHASE_BWD_GEMM 3
+#define SCTC_PHASE_BWD_REC 4
+#define SCTC_PHASE_OTHER 5
+#define SCTC_N_PHASES 6
+int sctc_brnn_set_profiling(sctc_brnn_t h, int32_t enable);
+int sctc_brnn_phase_ms(sctc_brnn_t h, float* ms_out /* [SCTC_N_PHASES] */);
+/* algorithmic FLOPs of one cost_and_grad over this minibatch, SURVEY 8(d) formula
+ * (total, and the part in the time-batched GEMMs / in the recurrent steps) */
+int sctc_brnn_flops(sctc_brnn_t h, const sctc_minibatch* mb, double* total, double* gemm,
+                    double* recurrent);
+
+/* cm.dot(A, B, target=C) of cudamat on row-major fp32 device matrices (brnnet.py:140 forward,
+ * :196 weight gradient, :204 delta propagation, :227-230 recurrent weight gradient):
+ *   C[M][N] = sum_k A(m,k) B(k,n) (+ bias[n]) (relu)
+ *   a_kcontig: A(m,k) = A[m*lda+k], else A[k*lda+m];  b_kcontig: B(k,n) = B[n*ldb+k], else B[k*ldb+n]
+ * fp32 operands, fp32 accumulate on the matrix cores (v_mfma_f32_32x32x2_f32).
+ * workspace (optional) enables deterministic split-K for small M*N. */
+int sctc_gemm_f32(const float* A_dev, int64_t lda, int32_t a_kcontig, const float* B_dev,
+                  int64_t ldb, int32_t b_kcontig, float* C_dev, int64_t ldc, int32_t M, int32_t N,
+                  int32_t K, const float* bias_dev, int32_t relu, void* workspace_dev,
+                  size_t workspace_bytes, void* stream);
+
+/* ---- what sgd.py needs from cudamat objects (sgd.py:21-23,93-106,129-141,161) ---- */
+
+/* y += alpha * x   (CUDAMatrix.add_mult, NNet.updateParams brnnet.py:251-256) */
+int sctc_axpy(float* y_dev, const float* x_dev, float alpha, int64_t n, void* stream);
+/* x *= alpha       (CUDAMatrix.mult) */
+int sctc_scale(float* x_dev, float alpha, int64_t n, void* stream);
+/* sum of squares of n floats into *out_dev (double); euclid_norm()**2 over the whole
+ * gradient stack in one launch instead of 14 host syncs (sgd.py:103-107) */
+int sctc_sumsq(const float* x_dev, int64_t n, double* out_dev, void* workspace_dev,
+               size_t workspace_bytes, void* stream);
+/* Fused Nesterov step of sgd.py:129-141,161 on the flat buffers:
+ *   alph = alpha * min(1, maxGNorm/gnorm)  with gnorm = sqrt(*sumsq_dev) * grad_scale
+ *   v = mom*v - alph*grad_scale*g ;  w += v                                             */
+int sctc_nesterov_step(float* w_dev, float* v_dev, const float* g_dev, int64_t n, float mom,
+                       float alpha, float max_gnorm, float grad_scale, const double* sumsq_dev,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCTC_H_ */

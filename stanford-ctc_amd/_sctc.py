@@ -1,0 +1,147 @@
+"""ctypes binding of libsctc_hip.so (include/sctc.h) -- the only way the host-side
+mirror reaches the GPU.  There is NO CPU fallback: if the library is missing this
+module raises, and every compute entry point raises when no HIP device is present.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsctc_hip.so")
+
+F32, F64 = 0, 1
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+vp = ctypes.c_void_p
+
+
+class CtcBatch(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("A", ctypes.c_int32), ("blank", ctypes.c_int32),
+                ("dtype", ctypes.c_int32), ("ld", ctypes.c_int64), ("T_b", c_i32p),
+                ("U_b", c_i32p), ("frame_off", c_i64p), ("labels", c_i32p),
+                ("label_off", c_i64p), ("rowbase_dev", vp)]
+
+
+class BrnnConfig(ctypes.Structure):
+    _fields_ = [("input_dim", ctypes.c_int32), ("output_dim", ctypes.c_int32),
+                ("layer_size", ctypes.c_int32), ("num_layers", ctypes.c_int32),
+                ("temporal_layer", ctypes.c_int32), ("max_frames", ctypes.c_int32),
+                ("max_utts", ctypes.c_int32), ("max_act", ctypes.c_float),
+                ("reg", ctypes.c_float), ("train", ctypes.c_int32)]
+
+
+class TensorInfo(ctypes.Structure):
+    _fields_ = [("offset", ctypes.c_int64), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("ld", ctypes.c_int32), ("kind", ctypes.c_int32)]
+
+
+class BrnnSizes(ctypes.Structure):
+    _fields_ = [("param_elems", ctypes.c_int64), ("param_count", ctypes.c_int64),
+                ("workspace_bytes", ctypes.c_size_t), ("n_tensors", ctypes.c_int32)]
+
+
+class Minibatch(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("T_b", c_i32p), ("feats_dev", vp), ("labels", c_i32p),
+                ("U_b", c_i32p)]
+
+
+N_PHASES = 6
+
+# name -> (restype, argtypes); every symbol include/sctc.h declares
+PROTOTYPES = {
+    "sctc_abi_version": (ctypes.c_int, []),
+    "sctc_last_error": (ctypes.c_char_p, []),
+    "sctc_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "sctc_device_info": (ctypes.c_int, [c_i32p, c_i32p, c_i64p, ctypes.c_char_p, ctypes.c_int]),
+    "sctc_selftest": (ctypes.c_int, [vp]),
+    "sctc_ctc_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(CtcBatch)]),
+    "sctc_ctc_loss_batch": (ctypes.c_int, [ctypes.POINTER(CtcBatch), vp, vp, vp, vp, vp,
+                                           ctypes.c_size_t, vp]),
+    "sctc_softmax_rows": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
+                                         vp]),
+    "sctc_argmax_rows": (ctypes.c_int, [vp, ctypes.c_int32, vp, ctypes.c_int64, ctypes.c_int32,
+                                        ctypes.c_int64, vp]),
+    "sctc_brnn_query": (ctypes.c_int, [ctypes.POINTER(BrnnConfig), ctypes.POINTER(BrnnSizes)]),
+    "sctc_brnn_create": (ctypes.c_int, [ctypes.POINTER(BrnnConfig), vp, vp, vp, ctypes.c_size_t,
+                                        ctypes.POINTER(vp)]),
+    "sctc_brnn_destroy": (ctypes.c_int, [vp]),
+    "sctc_brnn_tensor_info": (ctypes.c_int, [vp, ctypes.c_int32, ctypes.POINTER(TensorInfo)]),
+    "sctc_brnn_cost_and_grad": (ctypes.c_int, [vp, ctypes.POINTER(Minibatch), ctypes.c_int32,
+                                               c_f64p, c_i32p, c_f64p, vp]),
+    "sctc_brnn_cost_and_grad_async": (ctypes.c_int, [vp, ctypes.POINTER(Minibatch),
+                                                     ctypes.c_int32, vp, vp, vp]),
+    "sctc_brnn_forward": (ctypes.c_int, [vp, ctypes.POINTER(Minibatch), vp, vp]),
+    "sctc_brnn_set_profiling": (ctypes.c_int, [vp, ctypes.c_int32]),
+    "sctc_brnn_phase_ms": (ctypes.c_int, [vp, c_f32p]),
+    "sctc_brnn_flops": (ctypes.c_int, [vp, ctypes.POINTER(Minibatch), c_f64p, c_f64p, c_f64p]),
+    "sctc_gemm_f32": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int32, vp, ctypes.c_int64,
+                                     ctypes.c_int32, vp, ctypes.c_int64, ctypes.c_int32,
+                                     ctypes.c_int32, ctypes.c_int32, vp, ctypes.c_int32, vp,
+                                     ctypes.c_size_t, vp]),
+    "sctc_axpy": (ctypes.c_int, [vp, vp, ctypes.c_float, ctypes.c_int64, vp]),
+    "sctc_scale": (ctypes.c_int, [vp, ctypes.c_float, ctypes.c_int64, vp]),
+    "sctc_sumsq": (ctypes.c_int, [vp, ctypes.c_int64, vp, vp, ctypes.c_size_t, vp]),
+    "sctc_nesterov_step": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_float,
+                                          ctypes.c_float, ctypes.c_float, ctypes.c_float, vp,
+                                          vp]),
+}
+
+FLAG_SYNC_SKIP = 1
+FLAG_ACCUMULATE = 2
+
+_lib = None
+
+
+class SctcError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libsctc_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libsctc_hip.so is missing (%s): build it with `python -c 'import "
+                "__graft_entry__ as g; g.build()'` -- there is no CPU fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)          # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        if L.sctc_abi_version() != 1:
+            raise ImportError("libsctc_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc < 0:
+        msg = lib().sctc_last_error()
+        msg = msg.decode() if msg else ""
+        if rc == -1:
+            raise ValueError("%s: %s" % (what, msg))
+        raise SctcError("%s failed (rc=%d): %s" % (what, rc, msg))
+    return rc
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise SctcError("no HIP device visible: the stanford-ctc MI355X path has no CPU fallback")
+    return torch
+
+
+def current_stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def i32(arr):
+    return arr.ctypes.data_as(c_i32p)
+
+
+def i64(arr):
+    return arr.ctypes.data_as(c_i64p)

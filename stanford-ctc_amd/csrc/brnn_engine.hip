@@ -1,0 +1,816 @@
+// BRNN engine: NNet.costAndGrad (ctc_fast/nnets/brnnet.py:117-249) for a minibatch
+// of utterances, orchestrating the fp32 MFMA GEMM, the persistent recurrent kernel
+// and the CTC kernels on one HIP stream.  No device allocation happens here: the
+// caller provides the flat parameter / gradient buffers and one workspace.
+//
+// Data layout in HBM (all fp32, row-major, feature dimensions padded to 32):
+//   packed time-major minibatch: utterances sorted by length (longest first);
+//   frame t of the utterance with rank b is row rowbase[t] + b of every activation /
+//   delta matrix ([rows][ld]).  A time step of the recurrence therefore touches one
+//   contiguous block of rows, and the time-batched GEMMs see N = sum_b T_b frames.
+//   Parameters: tensor i of `stack` at params + offset_i, [rows_p][cols_p], zero padded.
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+#include "ctc_kernels.h"
+#include "elementwise.h"
+#include "gemm_f32.h"
+#include "recurrent.h"
+
+namespace sctc {
+int ctc_run_batch(const sctc_ctc_batch* bt, const void* probs, void* grad, double* cost,
+                  int32_t* skip, void* ws, size_t ws_bytes, hipStream_t stream, void* keep_stage);
+void* ctc_new_stage();
+void ctc_free_stage(void* p);
+}
+
+using namespace sctc;
+
+static constexpr int PAD = 32;
+static constexpr int CTC_LP_MAX = 2048;  // worst-case lattice row (2U+1 <= 2048)
+
+struct sctc_brnn {
+    sctc_brnn_config cfg;
+    int D, Dp, H, Hp, A, Ap, NL, TL;
+    int64_t maxF;
+    int maxB;
+    float* params;
+    float* grads;
+    std::vector<sctc_tensor_info> tinfo;  // stack order: W1,b1,...,W_{NL+1},b_{NL+1},(Wf,Wb)
+    int64_t param_elems, param_count;
+
+    // workspace carve-up
+    float* X0;
+    std::vector<float*> act;  // act[0] = X0, act[i] = output of layer i (i = 1..NL)
+    float *Z, *hF, *hB;       // temporal layer: pre-activation, forward / backward states
+    float *logits, *probs, *dlogits;
+    float *dA, *dBuf, *dF, *dBk;  // deltas: ping-pong pair + recurrent pair
+    int32_t *d_rowbase, *d_nact, *d_Ts, *d_src_row, *d_idx_lo, *d_idx_hi;
+    void* ctc_ws;
+    size_t ctc_ws_bytes;
+    float* splitk_ws;
+    int64_t splitk_floats;
+    float* colsum_ws;
+    float* xbuf;
+    unsigned* counters;
+    double* d_cost;   // [maxB] sorted order
+    int32_t* d_skip;  // [maxB]
+    double* d_cost_out;  // [maxB] caller order
+    int32_t* d_skip_out;
+    double* d_sumsq;  // [n weight tensors]
+    double* sumsq_ws;
+    int32_t* d_perm;  // [maxB] rank -> caller index
+
+    // per-call plan (host)
+    std::vector<int32_t> order, Ts, rowbase, nact, src_row, idx_lo, idx_hi;
+    int64_t N = 0;
+    int B = 0, Tmax = 0;
+    int64_t npairs = 0;
+
+    // profiling
+    int profiling = 0;
+    hipEvent_t ev[SCTC_N_PHASES + 1][2];
+    bool ev_ready = false;
+    float phase_ms[SCTC_N_PHASES];
+    int rec_sync_mode = 0;
+    // host staging of the CTC descriptors (must outlive the async uploads)
+    void* ctc_stage = nullptr;
+    std::vector<int32_t> ctc_U, ctc_labels;
+    std::vector<int64_t> ctc_frame_off, ctc_label_off;
+};
+
+static int weight_index(const sctc_brnn* h, int layer) { return 2 * layer; }      // W_{layer+1}
+static int bias_index(const sctc_brnn* h, int layer) { return 2 * layer + 1; }
+static int wf_index(const sctc_brnn* h) { return 2 * (h->NL + 1); }
+static int wb_index(const sctc_brnn* h) { return 2 * (h->NL + 1) + 1; }
+
+struct Dims {
+    int D, Dp, H, Hp, A, Ap, NL, TL;
+};
+
+static int derive_dims(const sctc_brnn_config* c, Dims* d)
+{
+    SCTC_CHECK_ARG(c, "brnn: null config");
+    SCTC_CHECK_ARG(c->input_dim >= 1 && c->output_dim >= 2 && c->layer_size >= 1 &&
+                       c->num_layers >= 1,
+                   "brnn: bad dimensions (inputDim %d outputDim %d layerSize %d numLayers %d)",
+                   c->input_dim, c->output_dim, c->layer_size, c->num_layers);
+    SCTC_CHECK_ARG(c->max_frames >= 1 && c->max_utts >= 1, "brnn: bad capacity");
+    SCTC_CHECK_ARG(c->output_dim <= 256, "brnn: alphabet %d > 256", c->output_dim);
+    d->D = c->input_dim;
+    d->H = c->layer_size;
+    d->A = c->output_dim;
+    d->NL = c->num_layers;
+    // brnnet.py:27-30
+    d->TL = (c->temporal_layer <= 0 || c->temporal_layer >= c->num_layers) ? -1 : c->temporal_layer;
+    d->Dp = (int)round_up(d->D, PAD);
+    d->Hp = (int)round_up(d->H, PAD);
+    d->Ap = (int)round_up(d->A, PAD);
+    if (d->TL > 0) {
+        char why[128];
+        if (!recurrent_supported(d->Hp, c->max_utts, why, sizeof(why)))
+            return set_error(SCTC_ERR_ARG, "brnn: %s", why);
+    }
+    return SCTC_OK;
+}
+
+static void build_tensor_table(const Dims& d, std::vector<sctc_tensor_info>* t, int64_t* elems,
+                               int64_t* count)
+{
+    t->clear();
+    int64_t off = 0, cnt = 0;
+    for (int l = 0; l <= d.NL; ++l) {
+        const int in = l == 0 ? d.D : d.H, inp = l == 0 ? d.Dp : d.Hp;
+        const int out = l == d.NL ? d.A : d.H, outp = l == d.NL ? d.Ap : d.Hp;
+        sctc_tensor_info w = {off, out, in, inp, 0};
+        t->push_back(w);
+        off += (int64_t)outp * inp;
+        sctc_tensor_info b = {off, out, 1, 1, 1};
+        t->push_back(b);
+        off += outp;
+        cnt += (int64_t)out * in + out;
+    }
+    if (d.TL > 0) {
+        for (int k = 0; k < 2; ++k) {
+            sctc_tensor_info w = {off, d.H, d.H, d.Hp, 2};
+            t->push_back(w);
+            off += (int64_t)d.Hp * d.Hp;
+            cnt += (int64_t)d.H * d.H;
+        }
+    }
+    *elems = off;
+    *count = cnt;
+}
+
+// lays the workspace out; with h == nullptr only measures
+static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void* ws, size_t bytes)
+{
+    Arena ar;
+    ar.init(ws ? ws : (void*)256, ws ? bytes : (size_t)-1 / 2);
+    const int64_t F = c->max_frames;
+    const int Bm = c->max_utts;
+    auto f = [&](int64_t n) { return ar.take<float>((size_t)n); };
+    float* X0 = f(F * d.Dp);
+    std::vector<float*> act(d.NL + 1);
+    act[0] = X0;
+    for (int i = 1; i <= d.NL; ++i) act[i] = f(F * d.Hp);
+    float *Z = nullptr, *hF = nullptr, *hB = nullptr;
+    if (d.TL > 0) { Z = f(F * d.Hp); hF = f(F * d.Hp); hB = f(F * d.Hp); }
+    float* logits = f(F * d.Ap);
+    float* probs = f(F * d.Ap);
+    float *dlogits = nullptr, *dA = nullptr, *dBuf = nullptr, *dF = nullptr, *dBk = nullptr;
+    if (c->train) {
+        dlogits = f(F * d.Ap);
+        dA = f(F * d.Hp);
+        dBuf = f(F * d.Hp);
+        if (d.TL > 0) { dF = f(F * d.Hp); dBk = f(F * d.Hp); }
+    }
+    int32_t* d_rowbase = ar.take<int32_t>(F);
+    int32_t* d_nact = ar.take<int32_t>(F);
+    int32_t* d_Ts = ar.take<int32_t>(Bm);
+    int32_t* d_src_row = ar.take<int32_t>(F);
+    int32_t* d_idx_lo = ar.take<int32_t>(F);
+    int32_t* d_idx_hi = ar.take<int32_t>(F);
+    int32_t* d_perm = ar.take<int32_t>(Bm);
+    // CTC workspace, worst case: every frame carries a CTC_LP_MAX-wide lattice row (x2)
+    size_t ctc_bytes = 0;
+    void* ctc_ws = nullptr;
+    if (c->train) {
+        ctc_bytes = align256(sizeof(CtcUtt) * Bm) + align256(sizeof(int32_t) * F) +
+                    align256(sizeof(double) * 2 * Bm) + align256(sizeof(int32_t) * 2 * Bm) +
+                    2 * align256(sizeof(float) * F * CTC_LP_MAX);
+        ctc_ws = ar.take<char>(ctc_bytes);
+    }
+    // split-K partials: worst case over the weight-gradient GEMMs
+    int64_t sk = 0;
+    if (c->train) {
+        for (int l = 0; l <= d.NL; ++l) {
+            const int inp = l == 0 ? d.Dp : d.Hp, outp = l == d.NL ? d.Ap : d.Hp;
+            int sp = 1;
+            sk = std::max<int64_t>(sk, gemm_plan_splits(outp, inp, (int)F, &sp));
+        }
+        if (d.TL > 0) {
+            int sp = 1;
+            sk = std::max<int64_t>(sk, gemm_plan_splits(d.Hp, d.Hp, (int)F, &sp));
+        }
+    }
+    float* splitk_ws = sk ? f(sk) : nullptr;
+    float* colsum_ws = c->train ? f(colsum_ws_floats(F, std::max(d.Hp, d.Ap))) : nullptr;
+    float* xbuf = d.TL > 0 ? f((int64_t)recurrent_xbuf_floats(d.Hp, Bm)) : nullptr;
+    unsigned* counters = ar.take<unsigned>(64);
+    double* d_cost = ar.take<double>(Bm);
+    int32_t* d_skip = ar.take<int32_t>(Bm);
+    double* d_cost_out = ar.take<double>(Bm);
+    int32_t* d_skip_out = ar.take<int32_t>(Bm);
+    double* d_sumsq = ar.take<double>(d.NL + 3);
+    double* sumsq_ws = ar.take<double>(sumsq_ws_bytes() / sizeof(double));
+    if (h && !ar.overflow) {
+        h->X0 = X0; h->act = act; h->Z = Z; h->hF = hF; h->hB = hB;
+        h->logits = logits; h->probs = probs; h->dlogits = dlogits;
+        h->dA = dA; h->dBuf = dBuf; h->dF = dF; h->dBk = dBk;
+        h->d_rowbase = d_rowbase; h->d_nact = d_nact; h->d_Ts = d_Ts; h->d_src_row = d_src_row;
+        h->d_idx_lo = d_idx_lo; h->d_idx_hi = d_idx_hi; h->d_perm = d_perm;
+        h->ctc_ws = ctc_ws; h->ctc_ws_bytes = ctc_bytes;
+        h->splitk_ws = splitk_ws; h->splitk_floats = sk; h->colsum_ws = colsum_ws;
+        h->xbuf = xbuf; h->counters = counters;
+        h->d_cost = d_cost; h->d_skip = d_skip; h->d_cost_out = d_cost_out;
+        h->d_skip_out = d_skip_out; h->d_sumsq = d_sumsq; h->sumsq_ws = sumsq_ws;
+    }
+    return ar.overflow && ws ? 0 : ar.used;
+}
+
+// ------------------------------------------------------------------ per-call plan
+
+static int make_plan(sctc_brnn* h, const sctc_minibatch* mb, bool need_labels, hipStream_t stream)
+{
+    SCTC_CHECK_ARG(mb && mb->T_b && mb->feats_dev, "brnn: null minibatch field");
+    SCTC_CHECK_ARG(mb->B >= 1 && mb->B <= h->maxB, "brnn: %d utterances, capacity %d", mb->B,
+                   h->maxB);
+    if (need_labels) SCTC_CHECK_ARG(mb->labels && mb->U_b, "brnn: labels required for training");
+    const int B = mb->B;
+    int64_t N = 0;
+    for (int b = 0; b < B; ++b) {
+        SCTC_CHECK_ARG(mb->T_b[b] >= 1, "brnn: utterance %d has no frames", b);
+        N += mb->T_b[b];
+    }
+    // setViews(): "Batch size exceeds max batch", brnnet.py:100
+    SCTC_CHECK_ARG(N <= h->maxF, "Batch size exceeds max batch (%lld frames > %lld)", (long long)N,
+                   (long long)h->maxF);
+    h->B = B;
+    h->N = N;
+    h->order.resize(B);
+    std::iota(h->order.begin(), h->order.end(), 0);
+    std::stable_sort(h->order.begin(), h->order.end(),
+                     [&](int a, int b) { return mb->T_b[a] > mb->T_b[b]; });
+    h->Ts.resize(B);
+    std::vector<int64_t> foff(B);
+    {
+        int64_t o = 0;
+        for (int b = 0; b < B; ++b) { foff[b] = o; o += mb->T_b[b]; }
+    }
+    for (int r = 0; r < B; ++r) h->Ts[r] = mb->T_b[h->order[r]];
+    const int Tmax = h->Ts[0];
+    h->Tmax = Tmax;
+    h->rowbase.assign(Tmax, 0);
+    h->nact.assign(Tmax, 0);
+    {
+        int na = B;
+        int64_t base = 0;
+        for (int t = 0; t < Tmax; ++t) {
+            while (na > 0 && h->Ts[na - 1] <= t) --na;
+            h->nact[t] = na;
+            h->rowbase[t] = (int32_t)base;
+            base += na;
+        }
+    }
+    h->src_row.resize(N);
+    h->idx_lo.clear();
+    h->idx_hi.clear();
+    for (int t = 0; t < Tmax; ++t)
+        for (int r = 0; r < h->nact[t]; ++r) {
+            const int row = h->rowbase[t] + r;
+            h->src_row[row] = (int32_t)(foff[h->order[r]] + t);
+            if (t >= 1) {
+                h->idx_hi.push_back(row);
+                h->idx_lo.push_back(h->rowbase[t - 1] + r);
+            }
+        }
+    h->npairs = (int64_t)h->idx_hi.size();
+    SCTC_HIP_TRY(hipMemcpyAsync(h->d_rowbase, h->rowbase.data(), sizeof(int32_t) * Tmax,
+                                hipMemcpyHostToDevice, stream));
+    SCTC_HIP_TRY(hipMemcpyAsync(h->d_nact, h->nact.data(), sizeof(int32_t) * Tmax,
+                                hipMemcpyHostToDevice, stream));
+    SCTC_HIP_TRY(hipMemcpyAsync(h->d_Ts, h->Ts.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice,
+                                stream));
+    SCTC_HIP_TRY(hipMemcpyAsync(h->d_src_row, h->src_row.data(), sizeof(int32_t) * N,
+                                hipMemcpyHostToDevice, stream));
+    SCTC_HIP_TRY(hipMemcpyAsync(h->d_perm, h->order.data(), sizeof(int32_t) * B,
+                                hipMemcpyHostToDevice, stream));
+    if (h->npairs > 0) {
+        SCTC_HIP_TRY(hipMemcpyAsync(h->d_idx_lo, h->idx_lo.data(), sizeof(int32_t) * h->npairs,
+                                    hipMemcpyHostToDevice, stream));
+        SCTC_HIP_TRY(hipMemcpyAsync(h->d_idx_hi, h->idx_hi.data(), sizeof(int32_t) * h->npairs,
+                                    hipMemcpyHostToDevice, stream));
+    }
+    return SCTC_OK;
+}
+
+// ------------------------------------------------------------------ phases / profiling
+
+struct PhaseTimer {
+    sctc_brnn* h;
+    hipStream_t s;
+    int cur = -1;
+    void begin(int phase)
+    {
+        if (!h->profiling) return;
+        end();
+        cur = phase;
+        (void)hipEventRecord(h->ev[SCTC_N_PHASES][0], s);
+    }
+    void end()
+    {
+        if (!h->profiling || cur < 0) return;
+        (void)hipEventRecord(h->ev[SCTC_N_PHASES][1], s);
+        (void)hipEventSynchronize(h->ev[SCTC_N_PHASES][1]);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, h->ev[SCTC_N_PHASES][0], h->ev[SCTC_N_PHASES][1]);
+        h->phase_ms[cur] += ms;
+        cur = -1;
+    }
+};
+
+static GemmArgs gemm_defaults()
+{
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.splits = 1;
+    g.add_scale = 0.f;
+    return g;
+}
+
+static const float* tensor_ptr(const sctc_brnn* h, const float* base, int idx)
+{
+    return base + h->tinfo[idx].offset;
+}
+
+// ------------------------------------------------------------------ forward
+
+static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, PhaseTimer& pt)
+{
+    const int64_t N = h->N;
+    pt.begin(SCTC_PHASE_OTHER);
+    // brnnet.py:136 hActs[0] <- data, here also the re-ordering into the packed layout
+    SCTC_TRY(launch_gather_rows(h->X0, h->Dp, mb->feats_dev, h->D, h->d_src_row, N, h->D, s));
+    for (int i = 1; i <= h->NL + 1; ++i) {
+        pt.begin(SCTC_PHASE_FWD_GEMM);
+        const int l = i - 1;
+        const sctc_tensor_info& wi = h->tinfo[weight_index(h, l)];
+        const int inp = l == 0 ? h->Dp : h->Hp;
+        const int outp = i == h->NL + 1 ? h->Ap : h->Hp;
+        GemmArgs g = gemm_defaults();
+        g.A = h->act[i - 1];           // [N][inp]
+        g.lda = inp;
+        g.a_kcontig = 1;
+        g.B = h->params + wi.offset;   // W [outp][inp]: B(k,n) = W[n][k]
+        g.ldb = inp;
+        g.b_kcontig = 1;
+        g.M = (int)N;
+        g.N = outp;
+        g.K = inp;
+        g.bias = tensor_ptr(h, h->params, bias_index(h, l));   // add_col_vec, brnnet.py:141
+        float* dst = i == h->NL + 1 ? h->logits : (i == h->TL ? h->Z : h->act[i]);
+        g.C = dst;
+        g.ldc = outp;
+        g.relu = (i <= h->NL && i != h->TL) ? 1 : 0;             // brnnet.py:155-157
+        SCTC_TRY(launch_gemm_f32(g, s));
+        if (i == h->TL) {
+            pt.begin(SCTC_PHASE_FWD_REC);
+            RecArgs r;
+            memset(&r, 0, sizeof(r));
+            r.W[0] = tensor_ptr(h, h->params, wf_index(h));
+            r.W[1] = tensor_ptr(h, h->params, wb_index(h));
+            r.ldw = h->Hp;
+            r.transpose = 0;
+            r.descending[0] = 0;
+            r.descending[1] = 1;
+            r.pre[0] = r.pre[1] = h->Z;
+            r.act[0] = r.act[1] = nullptr;
+            r.out[0] = h->hF;
+            r.out[1] = h->hB;
+            r.ld = h->Hp;
+            r.Hp = h->Hp;
+            r.B = h->B;
+            r.Bp = (int)round_up(h->B, 16);
+            r.Tmax = h->Tmax;
+            r.rowbase = h->d_rowbase;
+            r.nact = h->d_nact;
+            r.T_b = h->d_Ts;
+            r.max_act = h->cfg.max_act;
+            r.xbuf = h->xbuf;
+            r.counters = h->counters;
+            r.sync_mode = h->rec_sync_mode;
+            SCTC_TRY(launch_recurrent(r, s));
+            // hActs[i] = hActsFor + hActsBack, brnnet.py:153
+            SCTC_TRY(launch_add(h->act[i], h->hF, h->hB, N * h->Hp, s));
+        }
+    }
+    pt.begin(SCTC_PHASE_CTC);
+    SCTC_TRY(launch_softmax_rows(h->logits, h->probs, N, h->A, h->Ap, s));  // brnnet.py:161-168
+    return SCTC_OK;
+}
+
+static int check_recurrent_error(sctc_brnn* h, hipStream_t s)
+{
+    if (h->TL <= 0) return SCTC_OK;
+    unsigned e = 0;
+    SCTC_HIP_TRY(hipMemcpyAsync(&e, h->counters + 2, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    SCTC_HIP_TRY(hipStreamSynchronize(s));
+    if (e != 0)
+        return set_error(SCTC_ERR_TIMEOUT, "recurrent kernel: grid barrier timed out (are all %d "
+                         "workgroups co-resident?)", 2 * (h->Hp / 16));
+    return SCTC_OK;
+}
+
+// ------------------------------------------------------------------ CTC + backward
+
+static int run_ctc(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s)
+{
+    const int B = h->B;
+    std::vector<int32_t>& U = h->ctc_U;
+    std::vector<int32_t>& labels = h->ctc_labels;
+    std::vector<int64_t>& frame_off = h->ctc_frame_off;
+    std::vector<int64_t>& label_off = h->ctc_label_off;
+    U.assign(B, 0);
+    labels.clear();
+    frame_off.assign(B, 0);
+    label_off.assign(B, 0);
+    std::vector<int64_t> src_off(B);
+    {
+        int64_t o = 0;
+        for (int b = 0; b < B; ++b) { src_off[b] = o; o += mb->U_b[b]; }
+    }
+    for (int r = 0; r < B; ++r) {
+        const int b = h->order[r];
+        U[r] = mb->U_b[b];
+        frame_off[r] = r;  // rank in the packed layout
+        label_off[r] = (int64_t)labels.size();
+        labels.insert(labels.end(), mb->labels + src_off[b], mb->labels + src_off[b] + mb->U_b[b]);
+    }
+    sctc_ctc_batch bt;
+    bt.B = B;
+    bt.A = h->A;
+    bt.blank = 0;  // brnnet.py:175-176 blank=0
+    bt.dtype = SCTC_F32;
+    bt.ld = h->Ap;
+    bt.T_b = h->Ts.data();
+    bt.U_b = U.data();
+    bt.frame_off = frame_off.data();
+    bt.labels = labels.data();
+    bt.label_off = label_off.data();
+    bt.rowbase_dev = h->d_rowbase;
+    if (!h->ctc_stage) h->ctc_stage = ctc_new_stage();
+    return ctc_run_batch(&bt, h->probs, h->dlogits, h->d_cost, h->d_skip, h->ctc_ws,
+                         h->ctc_ws_bytes, s, h->ctc_stage);
+}
+
+__global__ void unpermute_results_kernel(const double* cost, const int32_t* skip,
+                                         const int32_t* perm, int B, double* cost_out,
+                                         int32_t* skip_out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < B) {
+        cost_out[perm[r]] = cost[r];
+        skip_out[perm[r]] = skip[r];
+    }
+}
+
+static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
+{
+    const int64_t N = h->N;
+    const int acc = (flags & SCTC_FLAG_ACCUMULATE) ? 1 : 0;
+    const float reg = h->cfg.reg;
+    const float* d_in = h->dlogits;
+    int d_in_ld = h->Ap;
+    float* bufs[2] = {h->dA, h->dBuf};
+    int which = 0;
+    for (int i = h->NL; i >= 0; --i) {          // brnnet.py:191-243
+        pt.begin(SCTC_PHASE_BWD_GEMM);
+        const sctc_tensor_info& wi = h->tinfo[weight_index(h, i)];
+        const int inp = i == 0 ? h->Dp : h->Hp;
+        const int outp = i == h->NL ? h->Ap : h->Hp;
+        const float* W = h->params + wi.offset;
+        // dW = deltasIn . hActs[i]^T (+ reg*W), brnnet.py:196-198
+        {
+            GemmArgs g = gemm_defaults();
+            g.A = d_in;             // A(m=out, k=frame) = d_in[frame][out]
+            g.lda = d_in_ld;
+            g.a_kcontig = 0;
+            g.B = h->act[i];        // B(k=frame, n=in) = act[frame][in]
+            g.ldb = inp;
+            g.b_kcontig = 0;
+            g.M = outp;
+            g.N = inp;
+            g.K = (int)N;
+            g.C = h->grads + wi.offset;
+            g.ldc = inp;
+            g.accumulate = acc;
+            if (reg > 0.f) { g.addend = W; g.ldadd = inp; g.add_scale = reg; }
+            g.splitk_ws = h->splitk_ws;
+            int splits = 1;
+            gemm_plan_splits(g.M, g.N, g.K, &splits);
+            g.splits = splits;
+            SCTC_TRY(launch_gemm_f32(g, s));
+        }
+        // db = deltasIn.sum(axis=1), brnnet.py:200
+        SCTC_TRY(launch_colsum(d_in, d_in_ld, N, outp,
+                               h->grads + h->tinfo[bias_index(h, i)].offset, acc, h->colsum_ws, s));
+        if (i == 0) break;
+        // deltasOut = W^T deltasIn, brnnet.py:204  (+ sign(hActs[i]) mask, :235-237)
+        float* d_out = bufs[which];
+        {
+            GemmArgs g = gemm_defaults();
+            g.A = d_in;             // [N][outp], K = outp
+            g.lda = d_in_ld;
+            g.a_kcontig = 1;
+            g.B = W;                // B(k=out, n=in) = W[out][in]
+            g.ldb = inp;
+            g.b_kcontig = 0;
+            g.M = (int)N;
+            g.N = inp;
+            g.K = outp;
+            g.C = d_out;
+            g.ldc = inp;
+            if (i != h->TL) { g.mask = h->act[i]; g.ldmask = h->Hp; }
+            SCTC_TRY(launch_gemm_f32(g, s));
+        }
+        if (i == h->TL) {
+            pt.begin(SCTC_PHASE_BWD_REC);
+            RecArgs r;
+            memset(&r, 0, sizeof(r));
+            r.W[0] = tensor_ptr(h, h->params, wf_index(h));
+            r.W[1] = tensor_ptr(h, h->params, wb_index(h));
+            r.ldw = h->Hp;
+            r.transpose = 1;
+            r.descending[0] = 1;   // deltasFor runs from T-1 down, brnnet.py:217-218
+            r.descending[1] = 0;   // deltasBack runs from 0 up,    brnnet.py:219-220
+            r.pre[0] = r.pre[1] = d_out;
+            r.act[0] = h->hF;
+            r.act[1] = h->hB;
+            r.out[0] = h->dF;
+            r.out[1] = h->dBk;
+            r.ld = h->Hp;
+            r.Hp = h->Hp;
+            r.B = h->B;
+            r.Bp = (int)round_up(h->B, 16);
+            r.Tmax = h->Tmax;
+            r.rowbase = h->d_rowbase;
+            r.nact = h->d_nact;
+            r.T_b = h->d_Ts;
+            r.max_act = h->cfg.max_act;
+            r.xbuf = h->xbuf;
+            r.counters = h->counters;
+            r.sync_mode = h->rec_sync_mode;
+            SCTC_TRY(launch_recurrent(r, s));
+            pt.begin(SCTC_PHASE_BWD_GEMM);
+            // dwtf = deltasFor[:,1:T] . hActsFor[:,0:T-1]^T ; dwtb = deltasBack[:,0:T-1] . hActsBack[:,1:T]^T
+            // (brnnet.py:227-230) over the (lo = frame t, hi = frame t+1) row pairs of every utterance
+            for (int k = 0; k < 2; ++k) {
+                const sctc_tensor_info& ri = h->tinfo[k == 0 ? wf_index(h) : wb_index(h)];
+                GemmArgs g = gemm_defaults();
+                g.A = k == 0 ? h->dF : h->dBk;
+                g.lda = h->Hp;
+                g.a_kcontig = 0;
+                g.idx_a = k == 0 ? h->d_idx_hi : h->d_idx_lo;
+                g.B = k == 0 ? h->hF : h->hB;
+                g.ldb = h->Hp;
+                g.b_kcontig = 0;
+                g.idx_b = k == 0 ? h->d_idx_lo : h->d_idx_hi;
+                g.M = h->Hp;
+                g.N = h->Hp;
+                g.K = (int)h->npairs;
+                g.C = h->grads + ri.offset;
+                g.ldc = h->Hp;
+                g.accumulate = acc;
+                if (reg > 0.f) {           // brnnet.py:244-247
+                    g.addend = h->params + ri.offset;
+                    g.ldadd = h->Hp;
+                    g.add_scale = reg;
+                }
+                g.splitk_ws = h->splitk_ws;
+                int splits = 1;
+                gemm_plan_splits(g.M, g.N, std::max(g.K, 1), &splits);
+                g.splits = splits;
+                SCTC_TRY(launch_gemm_f32(g, s));
+            }
+            // deltasOut = deltasFor + deltasBack, brnnet.py:233
+            SCTC_TRY(launch_add(d_out, h->dF, h->dBk, N * h->Hp, s));
+        }
+        d_in = d_out;
+        d_in_ld = h->Hp;
+        which ^= 1;
+    }
+    return SCTC_OK;
+}
+
+static int run_cost_and_grad(sctc_brnn* h, const sctc_minibatch* mb, int flags, hipStream_t s,
+                             bool* all_skipped)
+{
+    SCTC_CHECK_ARG(h && h->cfg.train, "brnn: model was created with train=0");
+    PhaseTimer pt{h, s};
+    if (h->profiling) memset(h->phase_ms, 0, sizeof(h->phase_ms));
+    SCTC_TRY(make_plan(h, mb, true, s));
+    SCTC_TRY(run_forward(h, mb, s, pt));
+    SCTC_TRY(run_ctc(h, mb, s));
+    hipLaunchKernelGGL(unpermute_results_kernel, dim3((h->B + 63) / 64), dim3(64), 0, s, h->d_cost,
+                       h->d_skip, h->d_perm, h->B, h->d_cost_out, h->d_skip_out);
+    *all_skipped = false;
+    if (flags & SCTC_FLAG_SYNC_SKIP) {
+        std::vector<int32_t> sk(h->B);
+        SCTC_HIP_TRY(hipMemcpyAsync(sk.data(), h->d_skip, sizeof(int32_t) * h->B,
+                                    hipMemcpyDeviceToHost, s));
+        SCTC_HIP_TRY(hipStreamSynchronize(s));
+        bool all = true;
+        for (int v : sk) all = all && v != 0;
+        *all_skipped = all;
+    }
+    if (!*all_skipped) SCTC_TRY(run_backward(h, flags, s, pt));
+    pt.end();
+    return SCTC_OK;
+}
+
+extern "C" {
+
+int sctc_brnn_query(const sctc_brnn_config* cfg, sctc_brnn_sizes* out)
+{
+    SCTC_CHECK_ARG(out, "brnn_query: null output");
+    Dims d;
+    SCTC_TRY(derive_dims(cfg, &d));
+    std::vector<sctc_tensor_info> t;
+    build_tensor_table(d, &t, &out->param_elems, &out->param_count);
+    out->n_tensors = (int32_t)t.size();
+    out->workspace_bytes = carve(cfg, d, nullptr, nullptr, 0);
+    return SCTC_OK;
+}
+
+int sctc_brnn_create(const sctc_brnn_config* cfg, float* params_dev, float* grads_dev,
+                     void* workspace_dev, size_t workspace_bytes, sctc_brnn_t* out)
+{
+    SCTC_CHECK_ARG(out && params_dev && workspace_dev, "brnn_create: null argument");
+    Dims d;
+    SCTC_TRY(derive_dims(cfg, &d));
+    SCTC_CHECK_ARG(!cfg->train || grads_dev, "brnn_create: train model needs a gradient buffer");
+    SCTC_CHECK_ARG(((uintptr_t)params_dev & 15) == 0 && ((uintptr_t)workspace_dev & 255) == 0,
+                   "brnn_create: params must be 16-byte and workspace 256-byte aligned");
+    sctc_brnn* h = new sctc_brnn();
+    h->cfg = *cfg;
+    h->D = d.D; h->Dp = d.Dp; h->H = d.H; h->Hp = d.Hp; h->A = d.A; h->Ap = d.Ap;
+    h->NL = d.NL; h->TL = d.TL;
+    h->maxF = cfg->max_frames;
+    h->maxB = cfg->max_utts;
+    h->params = params_dev;
+    h->grads = grads_dev;
+    build_tensor_table(d, &h->tinfo, &h->param_elems, &h->param_count);
+    const size_t need = carve(cfg, d, nullptr, nullptr, 0);
+    if (workspace_bytes < need) {
+        delete h;
+        return set_error(SCTC_ERR_WORKSPACE, "brnn_create: workspace %zu bytes < %zu needed",
+                         workspace_bytes, need);
+    }
+    carve(cfg, d, h, workspace_dev, workspace_bytes);
+    // padding columns of the CTC gradient are never written by the kernels: zero once
+    hipError_t e = hipSuccess;
+    if (cfg->train) e = hipMemset(h->dlogits, 0, sizeof(float) * h->maxF * h->Ap);
+    if (e != hipSuccess) {
+        delete h;
+        return set_error(SCTC_ERR_HIP, "brnn_create: %s", hipGetErrorString(e));
+    }
+    const char* sm = getenv("SCTC_REC_SYNC");
+    h->rec_sync_mode = sm ? atoi(sm) : 0;
+    *out = h;
+    return SCTC_OK;
+}
+
+int sctc_brnn_destroy(sctc_brnn_t h)
+{
+    if (!h) return SCTC_OK;
+    if (h->ev_ready)
+        for (int i = 0; i <= SCTC_N_PHASES; ++i) {
+            (void)hipEventDestroy(h->ev[i][0]);
+            (void)hipEventDestroy(h->ev[i][1]);
+        }
+    if (h->ctc_stage) ctc_free_stage(h->ctc_stage);
+    delete h;
+    return SCTC_OK;
+}
+
+int sctc_brnn_tensor_info(sctc_brnn_t h, int32_t index, sctc_tensor_info* out)
+{
+    SCTC_CHECK_ARG(h && out && index >= 0 && index < (int)h->tinfo.size(),
+                   "brnn_tensor_info: bad index %d", index);
+    *out = h->tinfo[index];
+    return SCTC_OK;
+}
+
+int sctc_brnn_cost_and_grad_async(sctc_brnn_t h, const sctc_minibatch* mb, int32_t flags,
+                                  double* cost_dev, int32_t* skip_dev, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    bool all_skipped = false;
+    SCTC_TRY(run_cost_and_grad(h, mb, flags, s, &all_skipped));
+    if (cost_dev)
+        SCTC_HIP_TRY(hipMemcpyAsync(cost_dev, h->d_cost_out, sizeof(double) * h->B,
+                                    hipMemcpyDeviceToDevice, s));
+    if (skip_dev)
+        SCTC_HIP_TRY(hipMemcpyAsync(skip_dev, h->d_skip_out, sizeof(int32_t) * h->B,
+                                    hipMemcpyDeviceToDevice, s));
+    return SCTC_OK;
+}
+
+int sctc_brnn_cost_and_grad(sctc_brnn_t h, const sctc_minibatch* mb, int32_t flags,
+                            double* cost_host, int32_t* skip_host, double* regcost_host,
+                            void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    bool all_skipped = false;
+    SCTC_TRY(run_cost_and_grad(h, mb, flags, s, &all_skipped));
+    int nw = 0;
+    if (regcost_host && h->cfg.reg > 0.f) {
+        // (reg/2) * sum ||w||^2 over every weight tensor incl. Wf, Wb (brnnet.py:178-183)
+        for (size_t i = 0; i < h->tinfo.size(); ++i) {
+            const sctc_tensor_info& t = h->tinfo[i];
+            if (t.kind == 1) continue;
+            const int64_t rows_p = round_up(t.rows, PAD);
+            SCTC_TRY(launch_sumsq(h->params + t.offset, rows_p * t.ld, h->d_sumsq + nw,
+                                  h->sumsq_ws, s));
+            ++nw;
+        }
+    }
+    if (cost_host)
+        SCTC_HIP_TRY(hipMemcpyAsync(cost_host, h->d_cost_out, sizeof(double) * h->B,
+                                    hipMemcpyDeviceToHost, s));
+    if (skip_host)
+        SCTC_HIP_TRY(hipMemcpyAsync(skip_host, h->d_skip_out, sizeof(int32_t) * h->B,
+                                    hipMemcpyDeviceToHost, s));
+    std::vector<double> ss(nw);
+    if (nw)
+        SCTC_HIP_TRY(hipMemcpyAsync(ss.data(), h->d_sumsq, sizeof(double) * nw,
+                                    hipMemcpyDeviceToHost, s));
+    SCTC_TRY(check_recurrent_error(h, s));  // synchronises the stream
+    if (regcost_host) {
+        double rc = 0.0;
+        for (double v : ss) rc += 0.5 * (double)h->cfg.reg * v;
+        *regcost_host = rc;
+    }
+    return SCTC_OK;
+}
+
+int sctc_brnn_forward(sctc_brnn_t h, const sctc_minibatch* mb, float* probs_dev, void* stream)
+{
+    SCTC_CHECK_ARG(h && probs_dev, "brnn_forward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    PhaseTimer pt{h, s};
+    if (h->profiling) memset(h->phase_ms, 0, sizeof(h->phase_ms));
+    SCTC_TRY(make_plan(h, mb, false, s));
+    SCTC_TRY(run_forward(h, mb, s, pt));
+    // probs back in the caller's per-utterance order, brnnet.py:170-173
+    SCTC_TRY(launch_scatter_rows(probs_dev, h->A, h->probs, h->Ap, h->d_src_row, h->N, h->A, s));
+    pt.end();
+    return check_recurrent_error(h, s);
+}
+
+int sctc_brnn_set_profiling(sctc_brnn_t h, int32_t enable)
+{
+    SCTC_CHECK_ARG(h, "null handle");
+    if (enable && !h->ev_ready) {
+        for (int i = 0; i <= SCTC_N_PHASES; ++i) {
+            SCTC_HIP_TRY(hipEventCreate(&h->ev[i][0]));
+            SCTC_HIP_TRY(hipEventCreate(&h->ev[i][1]));
+        }
+        h->ev_ready = true;
+    }
+    h->profiling = enable ? 1 : 0;
+    return SCTC_OK;
+}
+
+int sctc_brnn_phase_ms(sctc_brnn_t h, float* ms_out)
+{
+    SCTC_CHECK_ARG(h && ms_out, "null argument");
+    memcpy(ms_out, h->phase_ms, sizeof(h->phase_ms));
+    return SCTC_OK;
+}
+
+int sctc_brnn_flops(sctc_brnn_t h, const sctc_minibatch* mb, double* total, double* gemm,
+                    double* recurrent)
+{
+    SCTC_CHECK_ARG(h && mb && mb->T_b, "null argument");
+    // per utterance, multiply-add = 2, unpadded dimensions
+    double fg = 0.0, fr = 0.0;
+    for (int b = 0; b < mb->B; ++b) {
+        const double T = mb->T_b[b];
+        for (int l = 0; l <= h->NL; ++l) {
+            const double in = l == 0 ? h->D : h->H, out = l == h->NL ? h->A : h->H;
+            fg += 2.0 * out * in * T;              // forward
+            if (h->cfg.train) {
+                fg += 2.0 * out * in * T;          // weight gradient
+                if (l > 0) fg += 2.0 * out * in * T;  // delta propagation
+            }
+        }
+        if (h->TL > 0) {
+            const double HH = (double)h->H * h->H;
+            fr += 2.0 * 2.0 * HH * (T - 1);        // forward recurrence, two directions
+            if (h->cfg.train) {
+                fr += 2.0 * 2.0 * HH * (T - 1);    // BPTT
+                fg += 2.0 * 2.0 * HH * (T - 1);    // dWf, dWb (time-batched GEMMs)
+            }
+        }
+    }
+    if (total) *total = fg + fr;
+    if (gemm) *gemm = fg;
+    if (recurrent) *recurrent = fr;
+    return SCTC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,231 @@
+// C ABI: library housekeeping + the CTC entry points of include/sctc.h.
+#include <math.h>
+
+#include <vector>
+
+#include "common.h"
+#include "ctc_kernels.h"
+
+namespace sctc {
+
+char* err_buf()
+{
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int set_error(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int ctc_make_plan(int B, int A, int blank, const int32_t* T_b, const int32_t* U_b, size_t esz,
+                  CtcPlan* plan)
+{
+    SCTC_CHECK_ARG(B >= 1, "ctc: empty batch");
+    SCTC_CHECK_ARG(A >= 1 && A <= 256, "ctc: alphabet size %d not in [1,256]", A);
+    SCTC_CHECK_ARG(blank >= 0 && blank < A, "ctc: blank id %d outside the alphabet", blank);
+    int max_L = 0, max_T = 0;
+    int64_t n_labels = 0, frames = 0;
+    for (int b = 0; b < B; ++b) {
+        SCTC_CHECK_ARG(T_b[b] >= 1, "ctc: utterance %d has no frames", b);
+        // U == 0 is undefined behaviour in the reference (out-of-bounds read)
+        SCTC_CHECK_ARG(U_b[b] >= 1, "ctc: utterance %d has an empty label sequence", b);
+        max_L = std::max(max_L, 2 * U_b[b] + 1);
+        max_T = std::max(max_T, T_b[b]);
+        n_labels += U_b[b];
+        frames += T_b[b];
+    }
+    const int K = ctc_states_per_lane(max_L);
+    SCTC_CHECK_ARG(K > 0, "ctc: label sequence too long (2U+1 = %d > 2048)", max_L);
+    plan->B = B;
+    plan->A = A;
+    plan->blank = blank;
+    plan->K = K;
+    plan->lp = 64 * K;
+    plan->max_T = max_T;
+    plan->lat_elems = frames * plan->lp;
+    plan->n_labels = n_labels;
+    plan->bytes = align256(sizeof(CtcUtt) * B) + align256(sizeof(int32_t) * n_labels) +
+                  align256(sizeof(double) * 2 * B) + align256(sizeof(int32_t) * 2 * B) +
+                  2 * align256(esz * plan->lat_elems);
+    return SCTC_OK;
+}
+
+// `keep` (optional): caller-owned host staging that outlives the async uploads; without
+// it the function synchronises the stream before its local staging goes away.
+struct CtcHostStage {
+    std::vector<CtcUtt> utts;
+    std::vector<int32_t> labels;
+};
+
+template <typename R>
+static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs, R* grad,
+                   double* cost, int32_t* skip, void* ws, size_t ws_bytes, hipStream_t stream,
+                   CtcHostStage* keep)
+{
+    Arena ar;
+    ar.init(ws, ws_bytes);
+    CtcUtt* d_utts = ar.take<CtcUtt>(plan.B);
+    int32_t* d_labels = ar.take<int32_t>(plan.n_labels);
+    double* d_ll = ar.take<double>(2 * plan.B);
+    int32_t* d_skip2 = ar.take<int32_t>(2 * plan.B);
+    R* d_alpha = ar.take<R>(plan.lat_elems);
+    R* d_beta = ar.take<R>(plan.lat_elems);
+    if (ar.overflow)
+        return set_error(SCTC_ERR_WORKSPACE, "ctc: workspace %zu bytes < %zu needed", ws_bytes,
+                         ar.used);
+
+    CtcHostStage local;
+    CtcHostStage& st = keep ? *keep : local;
+    st.utts.resize(plan.B);
+    st.labels.resize(plan.n_labels);
+    std::vector<CtcUtt>& utts = st.utts;
+    std::vector<int32_t>& labels = st.labels;
+    int64_t lat_off = 0, lab_off = 0;
+    for (int b = 0; b < plan.B; ++b) {
+        CtcUtt& u = utts[b];
+        u.T = bt->T_b[b];
+        u.U = bt->U_b[b];
+        u.row0 = bt->frame_off[b];
+        u.lat_off = lat_off;
+        u.lab_off = lab_off;
+        const int32_t* src = bt->labels + bt->label_off[b];
+        for (int i = 0; i < u.U; ++i) {
+            SCTC_CHECK_ARG(src[i] >= 0 && src[i] < plan.A, "ctc: label %d of utterance %d is %d, "
+                           "outside the alphabet [0,%d)", i, b, src[i], plan.A);
+            labels[lab_off + i] = src[i];
+        }
+        lat_off += (int64_t)u.T * plan.lp;
+        lab_off += u.U;
+    }
+    SCTC_HIP_TRY(hipMemcpyAsync(d_utts, utts.data(), sizeof(CtcUtt) * plan.B,
+                                hipMemcpyHostToDevice, stream));
+    SCTC_HIP_TRY(hipMemcpyAsync(d_labels, labels.data(), sizeof(int32_t) * plan.n_labels,
+                                hipMemcpyHostToDevice, stream));
+
+    CtcLatticeArgs<R> la;
+    la.utts = d_utts;
+    la.probs = probs;
+    la.ld = bt->ld;
+    la.A = plan.A;
+    la.blank = plan.blank;
+    la.lp = plan.lp;
+    la.rowbase = bt->rowbase_dev;
+    la.labels = d_labels;
+    la.alpha = d_alpha;
+    la.beta = d_beta;
+    la.ll = d_ll;
+    la.skip2 = d_skip2;
+    SCTC_TRY(launch_ctc_lattice<R>(la, plan.B, plan.K, stream));
+
+    CtcGradArgs<R> ga;
+    ga.utts = d_utts;
+    ga.probs = probs;
+    ga.grad = grad;
+    ga.ld = bt->ld;
+    ga.A = plan.A;
+    ga.blank = plan.blank;
+    ga.lp = plan.lp;
+    ga.rowbase = bt->rowbase_dev;
+    ga.labels = d_labels;
+    ga.alpha = d_alpha;
+    ga.beta = d_beta;
+    ga.ll = d_ll;
+    ga.skip2 = d_skip2;
+    ga.cost = cost;
+    ga.skip = skip;
+    SCTC_TRY(launch_ctc_grad<R>(ga, plan.B, plan.max_T, stream));
+    // the pageable host staging must outlive the async copies
+    if (!keep) SCTC_HIP_TRY(hipStreamSynchronize(stream));
+    return SCTC_OK;
+}
+
+int ctc_run_batch(const sctc_ctc_batch* bt, const void* probs, void* grad, double* cost,
+                  int32_t* skip, void* ws, size_t ws_bytes, hipStream_t stream, void* keep_stage)
+{
+    CtcHostStage* keep = static_cast<CtcHostStage*>(keep_stage);
+    SCTC_CHECK_ARG(bt && probs && grad && cost && skip, "ctc: null argument");
+    SCTC_CHECK_ARG(bt->dtype == SCTC_F32 || bt->dtype == SCTC_F64, "ctc: bad dtype %d", bt->dtype);
+    SCTC_CHECK_ARG(bt->ld >= bt->A, "ctc: ld %lld < A %d", (long long)bt->ld, bt->A);
+    const size_t esz = bt->dtype == SCTC_F32 ? 4 : 8;
+    CtcPlan plan;
+    SCTC_TRY(ctc_make_plan(bt->B, bt->A, bt->blank, bt->T_b, bt->U_b, esz, &plan));
+    if (bt->dtype == SCTC_F32)
+        return run_ctc<float>(bt, plan, (const float*)probs, (float*)grad, cost, skip, ws,
+                              ws_bytes, stream, keep);
+    return run_ctc<double>(bt, plan, (const double*)probs, (double*)grad, cost, skip, ws,
+                           ws_bytes, stream, keep);
+}
+
+void* ctc_new_stage() { return new CtcHostStage(); }
+void ctc_free_stage(void* p) { delete static_cast<CtcHostStage*>(p); }
+
+}  // namespace sctc
+
+using namespace sctc;
+
+extern "C" {
+
+int sctc_abi_version(void) { return SCTC_ABI_VERSION; }
+
+const char* sctc_last_error(void) { return err_buf(); }
+
+int sctc_set_device(int device)
+{
+    SCTC_HIP_TRY(hipSetDevice(device));
+    return SCTC_OK;
+}
+
+int sctc_device_info(int* compute_units, int* lds_bytes_per_cu, int64_t* total_mem_bytes,
+                     char* name, int name_len)
+{
+    int dev = 0;
+    SCTC_HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    SCTC_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (total_mem_bytes) *total_mem_bytes = (int64_t)prop.totalGlobalMem;
+    if (name && name_len > 0) {
+        snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    return SCTC_OK;
+}
+
+size_t sctc_ctc_workspace_bytes(const sctc_ctc_batch* bt)
+{
+    if (!bt) return 0;
+    CtcPlan plan;
+    const size_t esz = bt->dtype == SCTC_F32 ? 4 : 8;
+    if (ctc_make_plan(bt->B, bt->A, bt->blank, bt->T_b, bt->U_b, esz, &plan) != SCTC_OK) return 0;
+    return plan.bytes;
+}
+
+int sctc_ctc_loss_batch(const sctc_ctc_batch* batch, const void* probs_dev, void* grad_dev,
+                        double* cost_dev, int32_t* skip_dev, void* workspace_dev,
+                        size_t workspace_bytes, void* stream)
+{
+    return ctc_run_batch(batch, probs_dev, grad_dev, cost_dev, skip_dev, workspace_dev,
+                         workspace_bytes, (hipStream_t)stream, nullptr);
+}
+
+int sctc_softmax_rows(const float* logits_dev, float* probs_dev, int64_t rows, int32_t A,
+                      int64_t ld, void* stream)
+{
+    SCTC_CHECK_ARG(logits_dev && probs_dev, "softmax_rows: null pointer");
+    return launch_softmax_rows(logits_dev, probs_dev, rows, A, ld, (hipStream_t)stream);
+}
+
+int sctc_argmax_rows(const void* probs_dev, int32_t dtype, int32_t* best_dev, int64_t rows,
+                     int32_t A, int64_t ld, void* stream)
+{
+    SCTC_CHECK_ARG(probs_dev && best_dev, "argmax_rows: null pointer");
+    return launch_argmax_rows(probs_dev, dtype, best_dev, rows, A, ld, (hipStream_t)stream);
+}
+
+}  // extern "C"

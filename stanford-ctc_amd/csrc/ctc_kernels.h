@@ -1,0 +1,68 @@
+// Host-visible declarations of the CTC kernels (ctc_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sctc {
+
+// per-utterance descriptor, uploaded by the host once per batch
+struct CtcUtt {
+    int32_t T, U;
+    int64_t row0;     // first row (contiguous layout) or rank in the packed minibatch
+    int64_t lat_off;  // element offset of this utterance's lattice
+    int64_t lab_off;  // first label in the concatenated label array
+};
+
+template <typename R>
+struct CtcLatticeArgs {
+    const CtcUtt* utts;
+    const R* probs;
+    int64_t ld;
+    int32_t A, blank, lp;
+    const int32_t* rowbase;  // nullable
+    const int32_t* labels;
+    R* alpha;
+    R* beta;
+    double* ll;      // [2B] llForward / llBackward
+    int32_t* skip2;  // [2B]
+};
+
+template <typename R>
+struct CtcGradArgs {
+    const CtcUtt* utts;
+    const R* probs;
+    R* grad;
+    int64_t ld;
+    int32_t A, blank, lp;
+    const int32_t* rowbase;
+    const int32_t* labels;
+    const R* alpha;
+    const R* beta;
+    const double* ll;
+    const int32_t* skip2;
+    double* cost;   // [B]
+    int32_t* skip;  // [B]
+};
+
+int ctc_states_per_lane(int max_L);  // K in {2,4,8,16,32}; 0 if 2U+1 > 2048
+template <typename R>
+int launch_ctc_lattice(const CtcLatticeArgs<R>& a, int B, int K, hipStream_t stream);
+template <typename R>
+int launch_ctc_grad(const CtcGradArgs<R>& a, int B, int max_T, hipStream_t stream);
+int launch_softmax_rows(const float* x, float* y, int64_t rows, int A, int64_t ld,
+                        hipStream_t stream);
+int launch_argmax_rows(const void* y, int dtype, int32_t* best, int64_t rows, int A, int64_t ld,
+                       hipStream_t stream);
+
+// Host-side driver shared by the C ABI and the BRNN engine: lays the descriptors
+// out in `ws`, uploads them and launches lattice + grad.
+struct CtcPlan {
+    int B = 0, A = 0, blank = 0, K = 0, lp = 0, max_T = 0;
+    int64_t lat_elems = 0;  // elements per lattice (alpha or beta)
+    int64_t n_labels = 0;
+    size_t bytes = 0;       // workspace bytes for this plan with element size esz
+};
+int ctc_make_plan(int B, int A, int blank, const int32_t* T_b, const int32_t* U_b, size_t esz,
+                  CtcPlan* plan);
+
+}  // namespace sctc

@@ -1,0 +1,480 @@
+// CTC forward-backward on gfx950: the device counterpart of
+// ctc_fast/ctc-loss/ctc_fast.pyx:13-152 (reference: Cython, CPU, float64).
+//
+// Three kernels per batch of utterances:
+//   softmax_rows   (brnnet.py:161-168)  logits -> probs, one wave per frame
+//   ctc_lattice    (ctc_fast.pyx:42-114) one wave64 per (utterance, direction):
+//                  the scaled alpha (dir 0) or beta (dir 1) recursion, serial in t,
+//                  parallel over the 2U+1 lattice states held K-per-lane in VGPRs;
+//                  s-1/s-2 neighbours arrive by one DPP wave shift, the per-frame
+//                  normaliser by a DPP reduction; the frame's probabilities are read
+//                  coalesced (lane k <- y[t][k]), prefetched PF frames ahead, and
+//                  gathered per state with ds_bpermute.  The scaled lattice row is
+//                  written with one vector store per lane per frame.
+//   ctc_grad       (ctc_fast.pyx:117-145) one wave per frame: alpha*beta products,
+//                  per-label sums in ascending-state order (bit-reproducible), the
+//                  y - g/(y*Z) formula.
+//
+// beta is computed as an alpha pass on the reversed problem: with s' = L-1-s and
+// tau = T-1-t the beta recursion of ctc_fast.pyx:85-114 is the alpha recursion of
+// :48-76 on the reversed label sequence (L = 2U+1 is odd, so blank/label parity is
+// preserved), and the band [start,end) maps onto itself.  Its lattice is stored in
+// s' order and read back reversed by ctc_grad.
+//
+// Scaling: like the reference every frame is renormalised by c_t = sum over the
+// band (ctc_fast.pyx:70-76).  We multiply by r_t = fl(1/c_t) and account
+// llForward -= log(r_t) in float64, which is exact for whatever r_t was applied.
+#include "common.h"
+#include "ctc_kernels.h"
+#include "xlane.h"
+
+namespace sctc {
+
+static constexpr int PF = 8;  // frames of probabilities prefetched ahead of the recursion
+
+template <typename R>
+struct Vec;
+template <>
+struct Vec<float> {
+    using v4 = float4;
+};
+template <>
+struct Vec<double> {
+    using v4 = double4;
+};
+
+// ---------------------------------------------------------------- softmax_rows
+
+template <int NA>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ y, int64_t rows,
+                                                           int A, int64_t ld)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ld;
+    float v[NA];
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+        int k = lane + 64 * q;
+        v[q] = k < A ? xr[k] : -INFINITY;
+        m = fmaxf(m, v[q]);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+        int k = lane + 64 * q;
+        v[q] = k < A ? expf(v[q] - m) : 0.f;
+        s += v[q];
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;  // cm.pow(rowVec,-1) then mult_by_row, brnnet.py:167-168
+    float* yr = y + row * ld;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+        int k = lane + 64 * q;
+        if (k < A) yr[k] = v[q] * inv;
+    }
+}
+
+int launch_softmax_rows(const float* x, float* y, int64_t rows, int A, int64_t ld,
+                        hipStream_t stream)
+{
+    if (rows <= 0) return SCTC_OK;
+    SCTC_CHECK_ARG(A >= 1 && A <= 256, "softmax_rows: alphabet %d not in [1,256]", A);
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (A <= 64)
+        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, block, 0, stream, x, y, rows, A, ld);
+    else if (A <= 128)
+        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, block, 0, stream, x, y, rows, A, ld);
+    else
+        hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, block, 0, stream, x, y, rows, A, ld);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+// ---------------------------------------------------------------- argmax_rows
+
+template <typename R>
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const R* __restrict__ y,
+                                                          int32_t* __restrict__ best,
+                                                          int64_t rows, int A, int64_t ld)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const R* yr = y + row * ld;
+    R bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = lane; k < A; k += 64) {
+        R v = yr[k];
+        if (v > bv) { bv = v; bi = k; }  // first maximum wins within the lane (np.argmax)
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        R ov = __shfl_xor(bv, off, 64);
+        int oi = __shfl_xor(bi, off, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) best[row] = bi == 0x7fffffff ? 0 : bi;
+}
+
+int launch_argmax_rows(const void* y, int dtype, int32_t* best, int64_t rows, int A, int64_t ld,
+                       hipStream_t stream)
+{
+    if (rows <= 0) return SCTC_OK;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == SCTC_F32)
+        hipLaunchKernelGGL(argmax_rows_kernel<float>, grid, block, 0, stream, (const float*)y,
+                           best, rows, A, ld);
+    else
+        hipLaunchKernelGGL(argmax_rows_kernel<double>, grid, block, 0, stream, (const double*)y,
+                           best, rows, A, ld);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+// ---------------------------------------------------------------- ctc_lattice
+
+__device__ __forceinline__ int64_t frame_row(const CtcUtt& u, const int32_t* rowbase, int t)
+{
+    return rowbase ? (int64_t)rowbase[t] + u.row0 : u.row0 + t;
+}
+
+// K states per lane (even), NA = ceil(A/64) probability registers per frame.
+template <typename R, int K, int NA>
+__global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<R> p)
+{
+    static_assert(K % 2 == 0 && K >= 2, "K must be even");
+    constexpr int KH = K / 2;
+    const int b = blockIdx.x;
+    const int dir = blockIdx.y;  // 0: alpha, 1: beta (== alpha of the reversed problem)
+    const int lane = threadIdx.x;
+    const CtcUtt u = p.utts[b];
+    const int T = u.T, U = u.U, L = 2 * U + 1;
+    const int LP = p.lp;  // lattice row stride (64*K)
+    R* lat = (dir == 0 ? p.alpha : p.beta) + u.lat_off;
+    const int32_t* seq = p.labels + u.lab_off;
+    const int blank = p.blank;
+
+    // ---- per-lane constants: labels of my odd states, skip-transition permission
+    int lab[KH];
+    bool allow[KH];
+    bool valid_lab[KH];
+#pragma unroll
+    for (int jj = 0; jj < KH; ++jj) {
+        const int idx = KH * lane + jj;  // label index of state K*lane + 2*jj + 1
+        const bool ok = idx < U;
+        const int i0 = ok ? (dir ? U - 1 - idx : idx) : 0;
+        lab[jj] = seq[i0];
+        int prev = blank;
+        if (ok && idx >= 1) prev = seq[dir ? U - idx : idx - 1];
+        // three-term transition only between different labels and not for s == 1
+        // (ctc_fast.pyx:64-68 / :103-107)
+        allow[jj] = ok && idx >= 1 && lab[jj] != prev;
+        valid_lab[jj] = ok;
+    }
+    // blank states K*lane + 2*jj exist while 2*(KH*lane+jj) <= 2U
+    bool valid_blk[KH];
+#pragma unroll
+    for (int jj = 0; jj < KH; ++jj) valid_blk[jj] = (KH * lane + jj) <= U;
+
+    const R* probs = p.probs;
+    const int64_t ld = p.ld;
+    const int A = p.A;
+
+    auto load_frame = [&](int tau, R (&dst)[NA]) {
+        const int t = dir ? T - 1 - tau : tau;
+        const R* yr = probs + frame_row(u, p.rowbase, t) * ld;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int k = lane + 64 * q;
+            dst[q] = k < A ? yr[k] : (R)0;
+        }
+    };
+    auto gather = [&](const R (&y)[NA], int k) -> R {
+        R out = lane_gather(y[0], k & 63);
+#pragma unroll
+        for (int q = 1; q < NA; ++q) {
+            R o = lane_gather(y[q], k & 63);
+            if ((k >> 6) == q) out = o;
+        }
+        return out;
+    };
+    auto bcast = [&](const R (&y)[NA], int k) -> R {
+        R out = lane_bcast(y[0], k & 63);
+#pragma unroll
+        for (int q = 1; q < NA; ++q) {
+            R o = lane_bcast(y[q], k & 63);
+            if ((k >> 6) == q) out = o;
+        }
+        return out;
+    };
+
+    R a[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = (R)0;
+
+    double ll = 0.0;   // per-lane partial of llForward (float64 like the reference)
+    R rslot = (R)1;    // scale factor of frame tau parked in lane (tau & 63)
+    int skip = 0;
+    bool inf_cost = false;
+
+    // ---- tau = 0: ctc_fast.pyx:42-47 / :79-84
+    R ycur[PF][NA];
+    {
+        R y0[NA];
+        load_frame(0, y0);
+        const R yb = bcast(y0, blank);
+        const R yl = gather(y0, lab[0]);
+        if (lane == 0) { a[0] = yb; a[1] = yl; }
+        R c = wave_sum(a[0] + a[1]);
+        if (c == (R)0) {
+            skip = 1;  // ZeroDivisionError at :45
+        } else {
+            const R r = (R)1 / c;
+            a[0] *= r;
+            a[1] *= r;
+            if (lane == 0) rslot = r;
+        }
+        typename Vec<R>::v4* dst = reinterpret_cast<typename Vec<R>::v4*>(lat + (int64_t)K * lane);
+        if constexpr (K % 4 == 0) {
+#pragma unroll
+            for (int j = 0; j < K; j += 4) dst[j / 4] = {a[j], a[j + 1], a[j + 2], a[j + 3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; ++j) lat[(int64_t)K * lane + j] = a[j];
+        }
+    }
+
+    if (!skip && T > 1) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int tau = 1 + i;
+            if (tau < T) load_frame(tau, ycur[i]);
+            else {
+#pragma unroll
+                for (int q = 0; q < NA; ++q) ycur[i][q] = (R)0;
+            }
+        }
+        for (int tb = 1; tb < T && !skip; tb += PF) {
+            R ynxt[PF][NA];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int tau = tb + PF + i;
+                if (tau < T) load_frame(tau, ynxt[i]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < NA; ++q) ynxt[i][q] = (R)0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int tau = tb + i;
+                if (tau < T && !skip) {
+                    // band limits, ctc_fast.pyx:49-54 (identical for the reversed problem)
+                    const int rem = 2 * (T - tau);
+                    const int start = L <= rem ? 0 : L - rem;
+                    const int end = min(2 * tau + 2, L);
+                    const R yb = bcast(ycur[i], blank);
+                    const R prev_last = lane_shr1(a[K - 1]);  // state K*lane - 1
+                    R n[K];
+#pragma unroll
+                    for (int jj = 0; jj < KH; ++jj) {
+                        // blank state s = K*lane + 2*jj  (:58-62)
+                        const R below = jj == 0 ? prev_last : a[2 * jj - 1];
+                        const int sb = K * lane + 2 * jj;
+                        R vb = (a[2 * jj] + below) * yb;
+                        n[2 * jj] = (valid_blk[jj] && sb >= start) ? vb : (R)0;
+                        // label state s = K*lane + 2*jj + 1  (:63-68)
+                        const R yl = gather(ycur[i], lab[jj]);
+                        R in = a[2 * jj + 1] + a[2 * jj];
+                        const R below2 = jj == 0 ? prev_last : a[2 * jj - 1];
+                        if (allow[jj]) in += below2;
+                        R vl = in * yl;
+                        n[2 * jj + 1] = (valid_lab[jj] && sb + 1 >= start) ? vl : (R)0;
+                    }
+                    R loc = n[0];
+#pragma unroll
+                    for (int j = 1; j < K; ++j) loc += n[j];
+                    const R c = wave_sum(loc);  // :71-73 (states >= end are exactly zero)
+                    if (c == (R)0) {
+                        if (start < end) {
+                            skip = 1;  // ZeroDivisionError at :75
+                        } else {
+                            inf_cost = true;  // empty band: nothing divided, log(0) = -inf
+#pragma unroll
+                            for (int j = 0; j < K; ++j) a[j] = n[j];
+                        }
+                    } else {
+                        const R r = (R)1 / c;
+#pragma unroll
+                        for (int j = 0; j < K; ++j) a[j] = n[j] * r;
+                        if (lane == (tau & 63)) rslot = r;
+                    }
+                    if (!skip) {
+                        R* row = lat + (int64_t)tau * LP + (int64_t)K * lane;
+                        if constexpr (K % 4 == 0) {
+                            typename Vec<R>::v4* dst = reinterpret_cast<typename Vec<R>::v4*>(row);
+#pragma unroll
+                            for (int j = 0; j < K; j += 4)
+                                dst[j / 4] = {a[j], a[j + 1], a[j + 2], a[j + 3]};
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < K; ++j) row[j] = a[j];
+                        }
+                        // every 64 frames fold the parked scale factors into ll
+                        if ((tau & 63) == 63) {
+                            ll -= log((double)rslot);
+                            rslot = (R)1;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+#pragma unroll
+                for (int q = 0; q < NA; ++q) ycur[i][q] = ynxt[i][q];
+        }
+    }
+    // frames whose scale factor is still parked
+    ll -= log((double)rslot);
+    double total = wave_sum(ll);
+    if (lane == 0) {
+        if (inf_cost) total = -INFINITY;  // math.log(0.0)
+        p.ll[2 * b + dir] = total;        // llForward (dir 0) / llBackward (dir 1)
+        p.skip2[2 * b + dir] = skip;
+    }
+}
+
+// ---------------------------------------------------------------- ctc_grad
+
+template <typename R>
+__global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<R> p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.y;
+    const CtcUtt u = p.utts[b];
+    const int T = u.T, U = u.U, L = 2 * U + 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int LP = p.lp;
+    const int t0 = blockIdx.x * 4;
+    if (t0 >= T) return;
+    int32_t* lab_s = reinterpret_cast<int32_t*>(smem);                    // [LP]
+    R* ab_s = reinterpret_cast<R*>(smem + (size_t)LP * sizeof(int32_t));   // [4][LP]
+
+    const int32_t* seq = p.labels + u.lab_off;
+    const int L4 = (L + 3) & ~3;  // vector reads below run to L4; pad label = -1 never matches
+    for (int s = threadIdx.x; s < L4; s += 256)
+        lab_s[s] = s >= L ? -1 : ((s & 1) ? seq[(s - 1) >> 1] : p.blank);
+    __syncthreads();
+
+    const int skip = p.skip2[2 * b] | p.skip2[2 * b + 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        p.cost[b] = -p.ll[2 * b];  // -llForward, ctc_fast.pyx:149,152
+        p.skip[b] = skip;
+    }
+    const int t = t0 + wave;
+    if (t >= T) return;
+    const int64_t row = frame_row(u, p.rowbase, t);
+    const R* yr = p.probs + row * p.ld;
+    R* gr = p.grad + row * p.ld;
+    if (skip) {
+        // the reference returns its zero-initialised grad (ctc_fast.pyx:31-32,149)
+        for (int k = lane; k < p.A; k += 64) gr[k] = (R)0;
+        return;
+    }
+    const R* al = p.alpha + u.lat_off + (int64_t)t * LP;
+    const R* be = p.beta + u.lat_off + (int64_t)(T - 1 - t) * LP;  // stored reversed in t and s
+    R* ab = ab_s + (size_t)wave * LP;
+    R zpart = (R)0;
+    for (int s = lane; s < L4; s += 64) {
+        R v = (R)0;
+        if (s < L) {
+            v = al[s] * be[L - 1 - s];                // :119
+            ab[s] = v;
+            if (v != (R)0) v = v / yr[lab_s[s]];       // :125-126 / :130-131
+        } else {
+            ab[s] = (R)0;
+        }
+        zpart += v;
+    }
+    const R Z = wave_sum(zpart);                        // absum[t], :133-136
+    // LDS writes above are read by other lanes of this wave only
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    using V4 = typename Vec<R>::v4;
+    const V4* ab4 = reinterpret_cast<const V4*>(ab);
+    const int4* lab4 = reinterpret_cast<const int4*>(lab_s);
+    for (int k = lane; k < p.A; k += 64) {
+        R g = (R)0;
+        for (int s4 = 0; s4 < L4 / 4; ++s4) {   // ascending s == the reference's order (:120-131)
+            const V4 v = ab4[s4];
+            const int4 l = lab4[s4];
+            if (l.x == k) g += v.x;
+            if (l.y == k) g += v.y;
+            if (l.z == k) g += v.z;
+            if (l.w == k) g += v.w;
+        }
+        const R y = yr[k];
+        const R tmp = y * Z;                        // :141
+        gr[k] = tmp > (R)0 ? y - g / tmp : y;       // :142-145
+    }
+}
+
+// ---------------------------------------------------------------- launchers
+
+template <typename R, int K>
+static int launch_lattice_k(const CtcLatticeArgs<R>& a, int B, int NA, hipStream_t stream)
+{
+    dim3 grid(B, 2), block(64);
+    if (NA == 1) hipLaunchKernelGGL((ctc_lattice_kernel<R, K, 1>), grid, block, 0, stream, a);
+    else if (NA == 2) hipLaunchKernelGGL((ctc_lattice_kernel<R, K, 2>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((ctc_lattice_kernel<R, K, 4>), grid, block, 0, stream, a);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+int ctc_states_per_lane(int max_L)
+{
+    for (int k = 2; k <= 32; k *= 2)
+        if (max_L <= 64 * k) return k;
+    return 0;
+}
+
+template <typename R>
+int launch_ctc_lattice(const CtcLatticeArgs<R>& a, int B, int K, hipStream_t stream)
+{
+    const int NA = a.A <= 64 ? 1 : (a.A <= 128 ? 2 : 4);
+    switch (K) {
+        case 2: return launch_lattice_k<R, 2>(a, B, NA, stream);
+        case 4: return launch_lattice_k<R, 4>(a, B, NA, stream);
+        case 8: return launch_lattice_k<R, 8>(a, B, NA, stream);
+        case 16: return launch_lattice_k<R, 16>(a, B, NA, stream);
+        case 32: return launch_lattice_k<R, 32>(a, B, NA, stream);
+    }
+    return set_error(SCTC_ERR_ARG, "ctc: label sequence too long (K=%d)", K);
+}
+
+template <typename R>
+int launch_ctc_grad(const CtcGradArgs<R>& a, int B, int max_T, hipStream_t stream)
+{
+    dim3 grid((max_T + 3) / 4, B), block(256);
+    size_t smem = (size_t)a.lp * sizeof(int32_t) + 4 * (size_t)a.lp * sizeof(R);
+    if (smem > 48 * 1024)
+        SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<R>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(ctc_grad_kernel<R>, grid, block, smem, stream, a);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+template int launch_ctc_lattice<float>(const CtcLatticeArgs<float>&, int, int, hipStream_t);
+template int launch_ctc_lattice<double>(const CtcLatticeArgs<double>&, int, int, hipStream_t);
+template int launch_ctc_grad<float>(const CtcGradArgs<float>&, int, int, hipStream_t);
+template int launch_ctc_grad<double>(const CtcGradArgs<double>&, int, int, hipStream_t);
+
+}  // namespace sctc

@@ -1,0 +1,259 @@
+// HBM-bound helpers around the GEMM / recurrent / CTC kernels: row gather/scatter
+// between the caller's per-utterance layout and the packed time-major minibatch,
+// elementwise sums, bias gradients, and the flat-buffer optimizer primitives that
+// replace the cudamat calls of sgd.py / NNet.updateParams.
+#include "common.h"
+#include "elementwise.h"
+
+namespace sctc {
+
+// dst[r][0..cols) = src[idx[r]][0..cols), zero for cols..ldd  (one wave per row)
+__global__ __launch_bounds__(256) void gather_rows_kernel(float* __restrict__ dst, int64_t ldd,
+                                                          const float* __restrict__ src,
+                                                          int64_t lds, const int32_t* idx,
+                                                          int64_t rows, int cols)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* s = src + (int64_t)idx[r] * lds;
+    float* d = dst + r * ldd;
+    for (int c = lane; c < ldd; c += 64) d[c] = c < cols ? s[c] : 0.f;
+}
+
+// dst[idx[r]][0..cols) = src[r][0..cols)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(float* __restrict__ dst, int64_t ldd,
+                                                           const float* __restrict__ src,
+                                                           int64_t lds, const int32_t* idx,
+                                                           int64_t rows, int cols)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* s = src + r * lds;
+    float* d = dst + (int64_t)idx[r] * ldd;
+    for (int c = lane; c < cols; c += 64) d[c] = s[c];
+}
+
+__global__ __launch_bounds__(256) void add_kernel(float4* __restrict__ out,
+                                                  const float4* __restrict__ a,
+                                                  const float4* __restrict__ b, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 x = a[i], y = b[i];
+        out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+}
+
+// stage 1 of the bias gradient (brnnet.py:200 deltasIn.sum(axis=1)):
+// partial[chunk][c] = sum over the chunk's rows of x[r][c]; fixed order => reproducible
+static constexpr int CS_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x,
+                                                             int64_t ld, int64_t rows, int cols,
+                                                             float* __restrict__ partial)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+    const int64_t r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += x[r * ld + c];
+    partial[(int64_t)blockIdx.y * cols + c] = s;
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial,
+                                                           int nchunks, int cols,
+                                                           float* __restrict__ out, int accumulate)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunks; ++k) s += partial[(int64_t)k * cols + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y,
+                                                   const float* __restrict__ x, float alpha,
+                                                   int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] += alpha * x[i];
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, float alpha, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        x[i] *= alpha;
+}
+
+// sum of squares, float64 accumulation, two deterministic stages
+static constexpr int SS_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, int64_t n,
+                                                            double* __restrict__ partial)
+{
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = x[i];
+        s += v * v;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ partial,
+                                                          int nblocks, double* __restrict__ out)
+{
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+
+// sgd.py:129-141,161 fused over the flat buffers (one pass instead of ~13)
+__global__ __launch_bounds__(256) void nesterov_kernel(float* __restrict__ w, float* __restrict__ v,
+                                                       const float* __restrict__ g, int64_t n,
+                                                       float mom, float alpha, float max_gnorm,
+                                                       float grad_scale,
+                                                       const double* __restrict__ sumsq)
+{
+    float alph = alpha;
+    if (sumsq) {
+        const double gnorm = sqrt(*sumsq) * (double)grad_scale;
+        if (gnorm > (double)max_gnorm) alph = (float)((double)alpha * ((double)max_gnorm / gnorm));
+    }
+    const float ga = alph * grad_scale;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float nv = mom * v[i] - ga * g[i];
+        v[i] = nv;
+        w[i] += nv;
+    }
+}
+
+static inline int grid_for(int64_t n)
+{
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+int launch_gather_rows(float* dst, int64_t ldd, const float* src, int64_t lds, const int32_t* idx,
+                       int64_t rows, int cols, hipStream_t s)
+{
+    if (rows <= 0) return SCTC_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dst,
+                       ldd, src, lds, idx, rows, cols);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+int launch_scatter_rows(float* dst, int64_t ldd, const float* src, int64_t lds,
+                        const int32_t* idx, int64_t rows, int cols, hipStream_t s)
+{
+    if (rows <= 0) return SCTC_OK;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dst,
+                       ldd, src, lds, idx, rows, cols);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+int launch_add(float* out, const float* a, const float* b, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return SCTC_OK;
+    SCTC_CHECK_ARG(n % 4 == 0, "add: element count must be a multiple of 4");
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, (float4*)out,
+                       (const float4*)a, (const float4*)b, n / 4);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+int64_t colsum_ws_floats(int64_t rows, int cols)
+{
+    return ((rows + CS_ROWS - 1) / CS_ROWS) * (int64_t)cols;
+}
+
+int launch_colsum(const float* x, int64_t ld, int64_t rows, int cols, float* out, int accumulate,
+                  float* ws, hipStream_t s)
+{
+    if (cols <= 0) return SCTC_OK;
+    const int nchunks = (int)((rows + CS_ROWS - 1) / CS_ROWS);
+    const int cb = (cols + 255) / 256;
+    if (nchunks > 0)
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cb, nchunks), dim3(256), 0, s, x, ld, rows,
+                           cols, ws);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, s, ws, nchunks, cols, out,
+                       accumulate);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+size_t sumsq_ws_bytes() { return sizeof(double) * SS_BLOCKS; }
+
+int launch_sumsq(const float* x, int64_t n, double* out, double* ws, hipStream_t s)
+{
+    const int blocks = (int)std::min<int64_t>(SS_BLOCKS, std::max<int64_t>(1, (n + 255) / 256));
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, s, x, n, ws);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, ws, blocks, out);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+}  // namespace sctc
+
+using namespace sctc;
+
+extern "C" {
+
+int sctc_axpy(float* y_dev, const float* x_dev, float alpha, int64_t n, void* stream)
+{
+    SCTC_CHECK_ARG(y_dev && x_dev && n >= 0, "axpy: bad argument");
+    if (n == 0) return SCTC_OK;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y_dev,
+                       x_dev, alpha, n);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+int sctc_scale(float* x_dev, float alpha, int64_t n, void* stream)
+{
+    SCTC_CHECK_ARG(x_dev && n >= 0, "scale: bad argument");
+    if (n == 0) return SCTC_OK;
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x_dev,
+                       alpha, n);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+int sctc_sumsq(const float* x_dev, int64_t n, double* out_dev, void* workspace_dev,
+               size_t workspace_bytes, void* stream)
+{
+    SCTC_CHECK_ARG(x_dev && out_dev && workspace_dev && n >= 0, "sumsq: bad argument");
+    if (workspace_bytes < sumsq_ws_bytes())
+        return set_error(SCTC_ERR_WORKSPACE, "sumsq: workspace %zu < %zu bytes", workspace_bytes,
+                         sumsq_ws_bytes());
+    return launch_sumsq(x_dev, n, out_dev, (double*)workspace_dev, (hipStream_t)stream);
+}
+
+int sctc_nesterov_step(float* w_dev, float* v_dev, const float* g_dev, int64_t n, float mom,
+                       float alpha, float max_gnorm, float grad_scale, const double* sumsq_dev,
+                       void* stream)
+{
+    SCTC_CHECK_ARG(w_dev && v_dev && g_dev && n >= 0, "nesterov_step: bad argument");
+    if (n == 0) return SCTC_OK;
+    hipLaunchKernelGGL(nesterov_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                       w_dev, v_dev, g_dev, n, mom, alpha, max_gnorm, grad_scale, sumsq_dev);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// fp32 MFMA GEMM used for every time-batched contraction of the BRNN
+// (brnnet.py:140 fwd, :196 wgrad, :204 dgrad, :227-230 recurrent wgrad;
+// the reference calls cm.dot == cuBLAS sgemm, fp32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sctc {
+
+// C[M][N] (row-major, ldc) = sum_k A(m,k) * B(k,n)   then the epilogue.
+//   a_kcontig : A(m,k) = A[m*lda + k]        else A(m,k) = A[ka(k)*lda + m]
+//   b_kcontig : B(k,n) = B[n*ldb + k]        else B(k,n) = B[kb(k)*ldb + n]
+//   ka(k) = idx_a ? idx_a[k] : k  (row gather along K, used by the recurrent wgrad)
+// Feature dimensions (the contiguous ones) must be multiples of 4 and 16-byte aligned.
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    int64_t lda, ldb, ldc;
+    int32_t M, N, K;
+    int32_t a_kcontig, b_kcontig;
+    const int32_t* idx_a;   // nullable, only for !a_kcontig
+    const int32_t* idx_b;   // nullable, only for !b_kcontig
+    // epilogue: v = acc (+ bias[n]) ; relu ; * (mask[m][n] > 0) ; + add_scale*addend[m][n] ; (C += v)
+    const float* bias;      // nullable [N]
+    const float* mask;      // nullable [M][ldmask]
+    int64_t ldmask;
+    const float* addend;    // nullable [M][ldadd]
+    int64_t ldadd;
+    float add_scale;
+    int32_t relu;
+    int32_t accumulate;
+    // split-K (deterministic two-pass): partials in `splitk_ws` ([splits][M][N] floats)
+    float* splitk_ws;
+    int32_t splits;
+};
+
+// picks the split-K factor; returns the workspace floats needed (0 when splits == 1)
+int64_t gemm_plan_splits(int M, int N, int K, int* splits);
+int launch_gemm_f32(GemmArgs a, hipStream_t stream);
+
+}  // namespace sctc

@@ -1,0 +1,281 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 fma
+// chain, 157 TFLOP/s dense peak -- MI355X has no TF32/xf32 path, so this IS the
+// matrix-core instruction for the reference's fp32 cm.dot calls).
+//
+// Tiling: 128x128 block tile, BK = 32, 256 threads = 4 waves in a 2x2 grid, each
+// wave owning a 64x64 sub-tile = 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs).
+// Operands are staged through LDS in [k][m] / [k][n] order so that an MFMA
+// fragment read (lane l -> element (k = l>>5, m = l&31)) is a conflict-free
+// ds_read_b32 over 32 consecutive floats.  K-contiguous operands are transposed on
+// the way into LDS (row stride 129: conflict-free scalar writes), row-contiguous
+// operands are written with ds_write_b128 (row stride 132).  Global loads of tile
+// t+1 are issued before the MFMAs of tile t and written to the other LDS buffer
+// afterwards: one workgroup barrier per K tile.  Two blocks per CU (2 waves/SIMD)
+// overlap one block's barrier/epilogue with the other's MFMAs.
+// Workgroup ids are remapped so that the blocks of one XCD walk the N tiles of one
+// A row-panel consecutively (panel stays in that XCD's 4 MiB L2).
+#include "common.h"
+#include "gemm_f32.h"
+
+namespace sctc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int BM = 128, BN = 128, BK = 32, NTHREADS = 256;
+static constexpr int LD_K = 129;  // LDS row stride for transposed (K-contiguous) operands
+static constexpr int LD_R = 132;  // LDS row stride for row-contiguous operands
+static constexpr int LDS_OPERAND = BK * LD_R;  // floats per operand per buffer (max of the two)
+
+__device__ __forceinline__ float gemm_epilogue(const GemmArgs& p, float v, int row, int col)
+{
+    if (p.bias) v += p.bias[col];
+    if (p.relu) v = fmaxf(v, 0.f);
+    if (p.mask) v = p.mask[(int64_t)row * p.ldmask + col] > 0.f ? v : 0.f;
+    if (p.addend) v += p.add_scale * p.addend[(int64_t)row * p.ldadd + col];
+    if (p.accumulate) v += p.C[(int64_t)row * p.ldc + col];
+    return v;
+}
+
+template <bool AK, bool BKC>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LDA = AK ? LD_K : LD_R;
+    constexpr int LDB = BKC ? LD_K : LD_R;
+    float* As = smem;                    // [2][BK][LDA]
+    float* Bs = smem + 2 * LDS_OPERAND;  // [2][BK][LDB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = p.M, N = p.N, K = p.K;
+    const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
+    const int nblk = mt * nt;
+    // XCD-aware, bijective remap (block b runs on XCD b % 8)
+    int swz;
+    {
+        const int bid = blockIdx.x, q = nblk / 8, r = nblk % 8, xcd = bid % 8;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int tile_n = swz % nt, tile_m = swz / nt;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // split-K range of this block
+    const int ktiles = (K + BK - 1) / BK;
+    const int per = (ktiles + p.splits - 1) / p.splits;
+    const int kt_beg = blockIdx.y * per;
+    const int kt_end = min(ktiles, kt_beg + per);
+
+    float4 ra[4], rb[4];
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = tid + NTHREADS * q;
+            if constexpr (AK) {
+                const int r = f >> 3, k = k0 + 4 * (f & 7), row = m0 + r;
+                ra[q] = (row < M && k < K)
+                            ? *reinterpret_cast<const float4*>(p.A + (int64_t)row * p.lda + k)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const int kr = f >> 5, k = k0 + kr, m = m0 + 4 * (f & 31);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < K && m < M) {
+                    const int64_t kk = p.idx_a ? p.idx_a[k] : k;
+                    v = *reinterpret_cast<const float4*>(p.A + kk * p.lda + m);
+                }
+                ra[q] = v;
+            }
+            if constexpr (BKC) {
+                const int r = f >> 3, k = k0 + 4 * (f & 7), row = n0 + r;
+                rb[q] = (row < N && k < K)
+                            ? *reinterpret_cast<const float4*>(p.B + (int64_t)row * p.ldb + k)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const int kr = f >> 5, k = k0 + kr, n = n0 + 4 * (f & 31);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < K && n < N) {
+                    const int64_t kk = p.idx_b ? p.idx_b[k] : k;
+                    v = *reinterpret_cast<const float4*>(p.B + kk * p.ldb + n);
+                }
+                rb[q] = v;
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* a = As + buf * LDS_OPERAND;
+        float* b = Bs + buf * LDS_OPERAND;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = tid + NTHREADS * q;
+            if constexpr (AK) {
+                const int r = f >> 3, kq = 4 * (f & 7);
+                a[(kq + 0) * LDA + r] = ra[q].x;
+                a[(kq + 1) * LDA + r] = ra[q].y;
+                a[(kq + 2) * LDA + r] = ra[q].z;
+                a[(kq + 3) * LDA + r] = ra[q].w;
+            } else {
+                const int kr = f >> 5, m = 4 * (f & 31);
+                *reinterpret_cast<float4*>(a + kr * LDA + m) = ra[q];
+            }
+            if constexpr (BKC) {
+                const int r = f >> 3, kq = 4 * (f & 7);
+                b[(kq + 0) * LDB + r] = rb[q].x;
+                b[(kq + 1) * LDB + r] = rb[q].y;
+                b[(kq + 2) * LDB + r] = rb[q].z;
+                b[(kq + 3) * LDB + r] = rb[q].w;
+            } else {
+                const int kr = f >> 5, n = 4 * (f & 31);
+                *reinterpret_cast<float4*>(b + kr * LDB + n) = rb[q];
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt_beg < kt_end) {
+        gload(kt_beg);
+        lstore(0);
+        __syncthreads();
+        int buf = 0;
+        const int kh = lane >> 5, li = lane & 31;
+        for (int kt = kt_beg; kt < kt_end; ++kt) {
+            const bool more = kt + 1 < kt_end;
+            if (more) gload(kt + 1);
+            const float* a = As + buf * LDS_OPERAND + kh * LDA + wm * 64 + li;
+            const float* b = Bs + buf * LDS_OPERAND + kh * LDB + wn * 64 + li;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a0 = a[kk * LDA], a1 = a[kk * LDA + 32];
+                const float b0 = b[kk * LDB], b1 = b[kk * LDB + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (more) lstore(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool partial = p.splits > 1;
+    float* out = partial ? p.splitk_ws + (int64_t)blockIdx.y * M * N : p.C;
+    const int64_t ldo = partial ? N : p.ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < M && col < N) {
+                    float v = acc[i][j][r];
+                    if (!partial) v = gemm_epilogue(p, v, row, col);
+                    out[(int64_t)row * ldo + col] = v;
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p)
+{
+    const int64_t total = (int64_t)p.M * p.N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int z = 0; z < p.splits; ++z) v += p.splitk_ws[z * total + i];  // fixed order
+        const int row = (int)(i / p.N), col = (int)(i % p.N);
+        p.C[(int64_t)row * p.ldc + col] = gemm_epilogue(p, v, row, col);
+    }
+}
+
+int64_t gemm_plan_splits(int M, int N, int K, int* splits)
+{
+    const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
+    const int ktiles = (K + BK - 1) / BK;
+    int s = 1;
+    // fewer tiles than ~2 per CU: split K until the grid fills the 256 CUs twice
+    if (mt * nt < 256) {
+        s = (512 + mt * nt - 1) / (mt * nt);
+        s = std::min(s, std::max(1, ktiles / 8));  // keep >= 8 K tiles per split
+        s = std::min(s, 64);
+        s = std::max(s, 1);
+    }
+    *splits = s;
+    return s > 1 ? (int64_t)s * M * N : 0;
+}
+
+int launch_gemm_f32(GemmArgs a, hipStream_t stream)
+{
+    if (a.M <= 0 || a.N <= 0) return SCTC_OK;
+    SCTC_CHECK_ARG(a.K >= 0, "gemm: negative K");
+    SCTC_CHECK_ARG(a.lda % 4 == 0 && a.ldb % 4 == 0, "gemm: lda/ldb must be multiples of 4");
+    SCTC_CHECK_ARG(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0,
+                   "gemm: operands must be 16-byte aligned");
+    if (a.a_kcontig) SCTC_CHECK_ARG(a.K % 4 == 0, "gemm: K must be a multiple of 4 (A K-contig)");
+    else SCTC_CHECK_ARG(a.M % 4 == 0, "gemm: M must be a multiple of 4 (A row-contig)");
+    if (a.b_kcontig) SCTC_CHECK_ARG(a.K % 4 == 0, "gemm: K must be a multiple of 4 (B K-contig)");
+    else SCTC_CHECK_ARG(a.N % 4 == 0, "gemm: N must be a multiple of 4 (B row-contig)");
+    if (a.splits < 1) a.splits = 1;
+    if (a.splits > 1) SCTC_CHECK_ARG(a.splitk_ws != nullptr, "gemm: split-K without workspace");
+    const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
+    dim3 grid(mt * nt, a.splits), block(NTHREADS);
+    const size_t smem = sizeof(float) * 4 * LDS_OPERAND;  // 2 operands x 2 buffers
+    void (*kern)(GemmArgs) = nullptr;
+    if (a.a_kcontig && a.b_kcontig) kern = gemm_f32_kernel<true, true>;
+    else if (a.a_kcontig && !a.b_kcontig) kern = gemm_f32_kernel<true, false>;
+    else if (!a.a_kcontig && a.b_kcontig) kern = gemm_f32_kernel<false, true>;
+    else kern = gemm_f32_kernel<false, false>;
+    static bool attr_set[4] = {false, false, false, false};
+    const int vi = (a.a_kcontig ? 2 : 0) + (a.b_kcontig ? 1 : 0);
+    if (!attr_set[vi]) {
+        SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set[vi] = true;
+    }
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, a);
+    SCTC_HIP_TRY(hipGetLastError());
+    if (a.splits > 1) {
+        const int64_t total = (int64_t)a.M * a.N;
+        int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        SCTC_HIP_TRY(hipGetLastError());
+    }
+    return SCTC_OK;
+}
+
+}  // namespace sctc
+
+// ---- C ABI: cm.dot(A, B, target=C) of cudamat as used by brnnet.py:140,196,204,227-230
+extern "C" int sctc_gemm_f32(const float* A_dev, int64_t lda, int32_t a_kcontig,
+                             const float* B_dev, int64_t ldb, int32_t b_kcontig, float* C_dev,
+                             int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias_dev,
+                             int32_t relu, void* workspace_dev, size_t workspace_bytes,
+                             void* stream)
+{
+    using namespace sctc;
+    SCTC_CHECK_ARG(A_dev && B_dev && C_dev, "gemm_f32: null pointer");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A_dev; g.lda = lda; g.a_kcontig = a_kcontig;
+    g.B = B_dev; g.ldb = ldb; g.b_kcontig = b_kcontig;
+    g.C = C_dev; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias_dev; g.relu = relu;
+    int splits = 1;
+    const int64_t need = gemm_plan_splits(M, N, K, &splits);
+    if (splits > 1 && workspace_dev && workspace_bytes >= (size_t)need * sizeof(float)) {
+        g.splits = splits;
+        g.splitk_ws = (float*)workspace_dev;
+    } else {
+        g.splits = 1;
+    }
+    return launch_gemm_f32(g, (hipStream_t)stream);
+}

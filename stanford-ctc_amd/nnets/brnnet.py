@@ -1,0 +1,305 @@
+"""Drop-in for ``ctc_fast/nnets/brnnet.py``: ``NNet`` -- a deep ReLU network in which
+one hidden layer is bi-directionally recurrent, trained with CTC -- running on the
+MI355X through libsctc_hip.so (include/sctc.h).  Same constructor, methods and
+attributes as the reference class (brnnet.py:8-277); what the methods launch is new:
+
+* every ``cm.dot`` becomes one fp32 MFMA GEMM over all frames of the minibatch,
+* the 2(T-1) ``mvdot_col_slice`` + ``minmax`` launches of the temporal layer
+  (brnnet.py:148-152) and their BPTT mirror (:215-224) become one persistent
+  weight-stationary kernel per pass,
+* softmax + CTC run on the device (no D2H/H2D of probs/deltas, brnnet.py:170,188).
+
+``costAndGrad(data, labels)`` keeps the reference's one-utterance semantics
+(returns ``(cost, grad, skip)``; ``grad`` is the model-owned gradient stack, stale on
+skip like brnnet.py:185-186).  ``costAndGradBatch`` is the minibatch extension
+(gradients summed over utterances).  There is no CPU fallback.
+"""
+import ctypes
+import pickle
+
+import numpy as np
+
+import _sctc
+import cudamat as cm
+
+
+class TensorStack(list):
+    """list of [w, b] CUDAMatrix pairs that are views into one flat device buffer"""
+    flat = None
+
+
+class NNet:
+
+    def __init__(self, inputDim, outputDim, layerSize, numLayers, maxBatch,
+                 train=True, temporalLayer=-1, reg=0.0, maxUtts=1):
+        cm.cublas_init()                      # brnnet.py:13 (fails here without the library)
+        self.outputDim = outputDim
+        self.inputDim = inputDim
+        self.layerSize = layerSize
+        self.numLayers = numLayers
+        self.layerSizes = [layerSize] * numLayers
+        self.maxBatch = maxBatch
+        self.maxUtts = maxUtts
+        self.train = train
+        self.reg = reg
+        self.regcost = 0.0
+        if not self.train:
+            np.seterr(all='ignore')           # brnnet.py:25-26
+        if temporalLayer <= 0 or temporalLayer >= numLayers:
+            self.temporalLayer = -1           # brnnet.py:27-30
+        else:
+            self.temporalLayer = temporalLayer
+        self.maxAct = 20.0                    # brnnet.py:32
+        self._h = None
+        self.stack = None
+        self.grad = None
+
+    # ------------------------------------------------------------------ set-up
+
+    def _config(self):
+        return _sctc.BrnnConfig(self.inputDim, self.outputDim, self.layerSize, self.numLayers,
+                                self.temporalLayer, int(self.maxBatch) * int(self.maxUtts),
+                                int(self.maxUtts), float(self.maxAct) if self.maxAct else 0.0,
+                                float(self.reg), 1 if self.train else 0)
+
+    def _allocate(self):
+        torch = _sctc.require_gpu()
+        L = _sctc.lib()
+        cfg = self._config()
+        sizes = _sctc.BrnnSizes()
+        _sctc.check(L.sctc_brnn_query(ctypes.byref(cfg), ctypes.byref(sizes)), "NNet")
+        self._cfg = cfg
+        self._params = torch.zeros(sizes.param_elems, dtype=torch.float32, device="cuda")
+        self._grads = (torch.zeros(sizes.param_elems, dtype=torch.float32, device="cuda")
+                       if self.train else None)
+        self._ws = torch.empty(sizes.workspace_bytes, dtype=torch.uint8, device="cuda")
+        h = ctypes.c_void_p()
+        rc = L.sctc_brnn_create(ctypes.byref(cfg), self._params.data_ptr(),
+                                self._grads.data_ptr() if self.train else None,
+                                self._ws.data_ptr(), sizes.workspace_bytes, ctypes.byref(h))
+        _sctc.check(rc, "NNet")
+        self._h = h
+        self._param_count = int(sizes.param_count)
+        infos = []
+        for i in range(sizes.n_tensors):
+            ti = _sctc.TensorInfo()
+            _sctc.check(L.sctc_brnn_tensor_info(h, i, ctypes.byref(ti)), "tensor_info")
+            infos.append(ti)
+        self._infos = infos
+        self.stack = self._make_stack(self._params)
+        if self.train:
+            self.grad = self._make_stack(self._grads)
+
+    def _make_stack(self, flat):
+        """[W1,b1]..[W_{NL+1},b_{NL+1}] (+[Wf,dummy],[Wb,dummy]), brnnet.py:58-59,71-72"""
+        torch = _sctc.require_gpu()
+        st = TensorStack()
+        st.flat = flat
+        mats = []
+        for ti in self._infos:
+            rows_p, ld = cm.padded_layout(ti.rows, ti.cols)
+            mats.append(cm.CUDAMatrix(_flat=flat[ti.offset:ti.offset + rows_p * ld],
+                                      _shape=(ti.rows, ti.cols)))
+        n_ff = 2 * (self.numLayers + 1)
+        for i in range(0, n_ff, 2):
+            st.append([mats[i], mats[i + 1]])
+        if self.temporalLayer > 0:
+            dummy = cm.empty((1, 1))          # shared zero "bias" of the temporal layer (:61-64)
+            st.append([mats[n_ff], dummy])
+            st.append([mats[n_ff + 1], dummy])
+        return st
+
+    def initParams(self):
+        """Initialize parameters using 6/sqrt(fanin+fanout) (brnnet.py:34-41,66-70).
+        Draws from np.random in the reference's order, so np.random.seed(s) gives the
+        reference's weights."""
+        sizes = [self.inputDim] + self.layerSizes + [self.outputDim]
+        scales = [np.sqrt(6) / np.sqrt(n + m) for n, m in zip(sizes[:-1], sizes[1:])]
+        host = [[np.random.rand(m, n) * 2 * s - s, np.zeros((m, 1))]
+                for n, m, s in zip(sizes[:-1], sizes[1:], scales)]
+        if self.temporalLayer > 0:
+            scale = np.sqrt(6) / np.sqrt(self.layerSize * 2)
+            host.append([2 * scale * np.random.rand(self.layerSize, self.layerSize) - scale, None])
+            host.append([2 * scale * np.random.rand(self.layerSize, self.layerSize) - scale, None])
+        self._allocate()
+        self.setParams(host)
+
+    def setParams(self, host_stack):
+        """host_stack: list of [w, b] NumPy arrays in stack order (b may be None)"""
+        if self._h is None:
+            self._allocate()
+        for (w, b), (hw, hb) in zip(self.stack, host_stack):
+            w.numpy_array = np.asarray(hw, dtype=np.float32)
+            w.copy_to_device()
+            if hb is not None and b.shape == np.asarray(hb).reshape(-1, 1).shape:
+                b.numpy_array = np.asarray(hb, dtype=np.float32).reshape(-1, 1)
+                b.copy_to_device()
+
+    def paramCount(self):
+        param_count = 0
+        for w, b in self.stack:
+            print(w.shape, b.shape)
+            param_count += np.prod(w.shape)
+            param_count += np.prod(b.shape)
+        return param_count
+
+    def setViews(self, batchSize):
+        """The reference slices its maxBatch-wide buffers here (brnnet.py:96-115); the
+        engine's workspace needs no views, only the capacity check remains."""
+        assert batchSize <= self.maxBatch, "Batch size exceeds max batch"
+
+    # ------------------------------------------------------------------ the hot path
+
+    def _stage(self, data_list):
+        """host (inputDim, T) arrays -> one device float32 [sum T][inputDim] block"""
+        torch = _sctc.require_gpu()
+        rows = []
+        for d in data_list:
+            d = np.asarray(d)
+            if d.ndim != 2 or d.shape[0] != self.inputDim:
+                raise ValueError("data must be (inputDim, T); got %s" % (d.shape,))
+            rows.append(np.ascontiguousarray(d.T, dtype=np.float32))
+        host = rows[0] if len(rows) == 1 else np.concatenate(rows, axis=0)
+        return torch.from_numpy(host).cuda()
+
+    def _minibatch(self, feats_dev, T_b, labels_list):
+        T_arr = np.ascontiguousarray(T_b, dtype=np.int32)
+        keep = [T_arr]
+        if labels_list is not None:
+            U_arr = np.ascontiguousarray([len(l) for l in labels_list], dtype=np.int32)
+            lab = np.ascontiguousarray(np.concatenate([np.asarray(l).reshape(-1)
+                                                       for l in labels_list]), dtype=np.int32)
+            keep += [U_arr, lab]
+            mb = _sctc.Minibatch(len(T_arr), _sctc.i32(T_arr), feats_dev.data_ptr(),
+                                 _sctc.i32(lab), _sctc.i32(U_arr))
+        else:
+            mb = _sctc.Minibatch(len(T_arr), _sctc.i32(T_arr), feats_dev.data_ptr(), None, None)
+        return mb, keep
+
+    def costAndGradBatch(self, data_list, labels_list, sync_skip=False, accumulate=False,
+                         feats_dev=None, T_b=None):
+        """Minibatch step.  Returns (costs float64[B], grad stack, skips bool[B]); the
+        gradient is the SUM over the non-skipped utterances.  `feats_dev`/`T_b` let the
+        caller pass features that already sit in HBM ([sum T][inputDim] float32)."""
+        if self._h is None:
+            raise RuntimeError("initParams() / fromFile() first")
+        if feats_dev is None:
+            T_b = [np.asarray(d).shape[1] for d in data_list]
+            feats_dev = self._stage(data_list)
+        for T in T_b:
+            self.setViews(T)
+        mb, keep = self._minibatch(feats_dev, T_b, labels_list)
+        B = len(T_b)
+        cost = np.zeros(B, dtype=np.float64)
+        skip = np.zeros(B, dtype=np.int32)
+        regcost = ctypes.c_double(0.0)
+        flags = (_sctc.FLAG_SYNC_SKIP if sync_skip else 0) | \
+                (_sctc.FLAG_ACCUMULATE if accumulate else 0)
+        rc = _sctc.lib().sctc_brnn_cost_and_grad(
+            self._h, ctypes.byref(mb), flags, cost.ctypes.data_as(_sctc.c_f64p),
+            skip.ctypes.data_as(_sctc.c_i32p), ctypes.byref(regcost), _sctc.current_stream_ptr())
+        _sctc.check(rc, "costAndGrad")
+        if self.reg > 0:
+            self.regcost = regcost.value            # brnnet.py:178-183
+        return cost, self.grad, skip.astype(bool)
+
+    def costAndGrad(self, data, labels=None, sentence=None):
+        T = data.shape[1]
+        self.setViews(T)
+        if not self.train:
+            return self.forwardProbs([data])[0]     # brnnet.py:171-173
+        cost, grad, skip = self.costAndGradBatch([data], [labels], sync_skip=True)
+        c = float(cost[0])
+        if self.reg > 0:
+            c = c + self.regcost                    # added even when skipped (brnnet.py:178-186)
+        return c, self.grad, bool(skip[0])
+
+    def forwardProbs(self, data_list):
+        """train=False path for a list of utterances -> list of float32 (outputDim, T) probs"""
+        torch = _sctc.require_gpu()
+        if self._h is None:
+            raise RuntimeError("initParams() / fromFile() first")
+        T_b = [np.asarray(d).shape[1] for d in data_list]
+        feats = self._stage(data_list)
+        mb, keep = self._minibatch(feats, T_b, None)
+        out = torch.empty((int(sum(T_b)), self.outputDim), dtype=torch.float32, device="cuda")
+        rc = _sctc.lib().sctc_brnn_forward(self._h, ctypes.byref(mb), out.data_ptr(),
+                                           _sctc.current_stream_ptr())
+        _sctc.check(rc, "costAndGrad(train=False)")
+        host = out.cpu().numpy()
+        res, o = [], 0
+        for T in T_b:
+            res.append(np.asfortranarray(host[o:o + T].T))
+            o += T
+        return res
+
+    def updateParams(self, scale, update):
+        """w += scale*dw, b += scale*db for every pair (brnnet.py:251-256).  When `update`
+        is a stack over one flat buffer this is a single launch."""
+        if isinstance(update, TensorStack) and update.flat is not None \
+                and update.flat.numel() == self._params.numel():
+            _sctc.check(_sctc.lib().sctc_axpy(self._params.data_ptr(), update.flat.data_ptr(),
+                                              float(scale), self._params.numel(),
+                                              _sctc.current_stream_ptr()), "updateParams")
+            return
+        for params, paramsDel in zip(self.stack, update):
+            w, b = params
+            dw, db = paramsDel
+            w.add_mult(dw, alpha=scale)
+            b.add_mult(db, alpha=scale)
+
+    def zerosLikeStack(self):
+        """a fresh stack (e.g. the SGD velocity, sgd.py:21-23) over one flat buffer"""
+        torch = _sctc.require_gpu()
+        return self._make_stack(torch.zeros_like(self._params))
+
+    # ------------------------------------------------------------------ checkpoint (brnnet.py:258-277)
+
+    def toFile(self, fid):
+        """Saves only the network parameters to the given fd."""
+        stack = []
+        for w, b in self.stack:
+            w.copy_to_host()
+            b.copy_to_host()
+            stack.append([w.numpy_array, b.numpy_array])
+        pickle.dump(stack, fid)
+
+    def fromFile(self, fid):
+        stack = pickle.load(fid)
+        if self._h is None:
+            self._allocate()
+        for (w, b), (wi, bi) in zip(self.stack, stack):
+            w.numpy_array = np.array(wi, dtype=np.float32)
+            b.numpy_array = np.array(bi, dtype=np.float32).reshape(b.shape)
+            w.copy_to_device()
+            b.copy_to_device()
+
+    def check_grad(self, data, labels, epsilon=1e-3):
+        """forward-difference gradient check on a corner of every weight (brnnet.py:279-297)"""
+        cost, grad, _ = self.costAndGrad(data, labels)
+        worst = 0.0
+        for param, delta in zip(self.stack, grad):
+            w, b = param
+            dw, db = delta
+            dw.copy_to_host()
+            w.copy_to_host()
+            analytic = dw.numpy_array.copy()
+            for i in range(min(w.shape[0], 3)):
+                for j in range(min(w.shape[1], 3)):
+                    w.numpy_array[i, j] += epsilon
+                    w.copy_to_device()
+                    costP, _, _ = self.costAndGrad(data, labels)
+                    numGrad = (costP - cost) / epsilon
+                    w.numpy_array[i, j] -= epsilon
+                    w.copy_to_device()
+                    print("Analytic %f, Numeric %f" % (analytic[i, j], numGrad))
+                    worst = max(worst, abs(analytic[i, j] - numGrad))
+        return worst
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _sctc.lib().sctc_brnn_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""GPU diagnostics (not a test): device info, kernel micro-timings, phase breakdown of
+the cfg-3 step.  Writes to stdout; run on the GPU box:  python tests/gpu_diag.py [sections]"""
+import ctypes
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "stanford-ctc_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+import _sctc  # noqa: E402
+
+PHASES = ["fwd_gemm", "fwd_rec", "ctc", "bwd_gemm", "bwd_rec", "other"]
+
+
+def timed(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def sec_info():
+    L = _sctc.lib()
+    cu, lds, mem = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+    name = ctypes.create_string_buffer(128)
+    L.sctc_device_info(ctypes.byref(cu), ctypes.byref(lds), ctypes.byref(mem), name, 128)
+    print("device:", name.value.decode(), "CUs", cu.value, "LDS/CU", lds.value, "mem GB",
+          mem.value / 2 ** 30)
+    print("host cores:", os.cpu_count())
+    print("selftest mask:", L.sctc_selftest(None))
+
+
+def sec_gemm():
+    L = _sctc.lib()
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    for (M, N, K, akc, bkc, tag) in ((32000, 1824, 1824, 1, 1, "fwd NT"),
+                                     (32000, 1824, 1824, 1, 0, "dgrad NN"),
+                                     (1824, 1824, 32000, 0, 0, "wgrad TN"),
+                                     (32000, 1824, 512, 1, 1, "fwd in-layer"),
+                                     (64, 1824, 32000, 0, 0, "wgrad out-layer (split-K)"),
+                                     (8192, 8192, 8192, 1, 1, "square 8k NT")):
+        a = torch.randn((M, K) if akc else (K, M), device="cuda")
+        b = torch.randn((N, K) if bkc else (K, N), device="cuda")
+        c = torch.empty((M, N), device="cuda")
+
+        def run():
+            rc = L.sctc_gemm_f32(a.data_ptr(), a.shape[1], akc, b.data_ptr(), b.shape[1], bkc,
+                                 c.data_ptr(), N, M, N, K, None, 0, ws.data_ptr(), ws.numel(), None)
+            assert rc == 0, L.sctc_last_error()
+        ms = timed(run)
+        print("gemm %-28s M=%d N=%d K=%d: %.3f ms  %.1f TFLOP/s" %
+              (tag, M, N, K, ms, 2.0 * M * N * K / ms / 1e9))
+        del a, b, c
+
+
+def sec_ctc():
+    import ctc_fast
+    rs = np.random.RandomState(0)
+    for (B, T, U, A) in ((32, 1000, 100, 33), (1, 1000, 100, 33), (256, 1000, 100, 33),
+                         (32, 2000, 200, 33), (8, 8000, 800, 33)):
+        logits = torch.randn(B * T, A, device="cuda")
+        probs = torch.softmax(logits, dim=1).contiguous()
+        seqs = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
+
+        def run():
+            ctc_fast.ctc_loss_batch(probs, seqs, lengths=[T] * B)
+        ms = timed(run, iters=3, warm=1)
+        alg = B * (8.0 * A * T + 4 * U + 8)
+        print("ctc f32 B=%d T=%d U=%d: %.3f ms (incl. host wrapper)  alg %.2f MB -> %.1f GB/s" %
+              (B, T, U, ms, alg / 1e6, alg / ms / 1e6))
+
+
+def sec_brnn(cfgname="cfg3", B=32, sync=None):
+    from nnets import brnnet
+    cfgs = {"cfg1": (615, 28, 512, 2, 1, 200, 20), "cfg2": (943, 62, 1024, 3, 2, 300, 30),
+            "cfg3": (483, 33, 1824, 5, 3, 1000, 100), "cfg4": (615, 33, 1824, 5, 3, 2000, 200),
+            "cfg5": (615, 33, 2048, 7, 4, 8000, 800)}
+    D, A, H, NL, TL, T, U = cfgs[cfgname]
+    if sync is not None:
+        os.environ["SCTC_REC_SYNC"] = str(sync)
+    np.random.seed(0)
+    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B)
+    net.initParams()
+    rs = np.random.RandomState(1)
+    feats = torch.randn(B * T, D, device="cuda")
+    labels = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
+    Ts = [T] * B
+    L = _sctc.lib()
+
+    def run():
+        c, g, s = net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+        return c, s
+    t0 = time.time()
+    c, s = run()
+    torch.cuda.synchronize()
+    print("%s B=%d sync=%s first call %.1f ms; cost[0]=%.4f skip=%d" %
+          (cfgname, B, os.environ.get("SCTC_REC_SYNC", "0"), (time.time() - t0) * 1e3, c[0], s.sum()))
+    ms = timed(lambda: run(), iters=3, warm=1)
+    tot, gm, rc = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    mb, keep = net._minibatch(feats, Ts, labels)
+    L.sctc_brnn_flops(net._h, ctypes.byref(mb), ctypes.byref(tot), ctypes.byref(gm), ctypes.byref(rc))
+    print("  step %.2f ms -> %.0f frames/s, %.1f TFLOP/s overall (%.2f TFLOP: gemm %.2f rec %.2f)" %
+          (ms, B * T / ms * 1e3, tot.value / ms / 1e9, tot.value / 1e12, gm.value / 1e12, rc.value / 1e12))
+    L.sctc_brnn_set_profiling(net._h, 1)
+    run()
+    arr = (ctypes.c_float * 6)()
+    L.sctc_brnn_phase_ms(net._h, arr)
+    print("  phases ms:", ", ".join("%s %.2f" % (n, v) for n, v in zip(PHASES, arr)))
+    L.sctc_brnn_set_profiling(net._h, 0)
+    del net
+
+
+def main():
+    want = sys.argv[1:] or ["info", "gemm", "ctc", "brnn"]
+    table = {"info": sec_info, "gemm": sec_gemm, "ctc": sec_ctc,
+             "brnn": lambda: sec_brnn("cfg3", 32, 0),
+             "brnn1": lambda: sec_brnn("cfg3", 32, 1),
+             "brnn_small": lambda: sec_brnn("cfg2", 1, 0),
+             "brnn4": lambda: sec_brnn("cfg4", 32, 0)}
+    for name in want:
+        print("==== %s" % name, flush=True)
+        try:
+            table[name]()
+        except Exception:
+            traceback.print_exc()
+        sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+"""CPU-side checks of the drop-in boundary: libsctc_hip.so loads here (no GPU) and
+exports exactly the functions include/sctc.h declares; the ctypes struct mirrors
+match the C structs; the host-side mirror exposes the reference's names and fails
+loudly (no fallback) without a GPU.  No compute calls."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sctc.h")
+
+
+@pytest.fixture(scope="module")
+def sctc():
+    import __graft_entry__ as ge
+    import _sctc
+    if not os.path.exists(_sctc.LIB_PATH):
+        ge.build()
+    return _sctc
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sctc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(sctc):
+    L = sctc.lib()
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), "libsctc_hip.so does not export %s" % n
+    assert sorted(sctc.PROTOTYPES) == names, "ctypes prototypes out of sync with include/sctc.h"
+    assert L.sctc_abi_version() == 1
+
+
+def test_struct_mirrors_match_the_header(sctc, tmp_path):
+    """compile a tiny C program against include/sctc.h and compare sizeof/offsetof"""
+    prog = tmp_path / "sz.c"
+    prog.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "sctc.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sctc_ctc_batch),'
+        ' offsetof(sctc_ctc_batch, rowbase_dev), sizeof(sctc_brnn_config),'
+        ' offsetof(sctc_brnn_config, train), sizeof(sctc_tensor_info), sizeof(sctc_brnn_sizes),'
+        ' sizeof(sctc_minibatch), offsetof(sctc_minibatch, U_b)); return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(sctc.CtcBatch), sctc.CtcBatch.rowbase_dev.offset,
+            ctypes.sizeof(sctc.BrnnConfig), sctc.BrnnConfig.train.offset,
+            ctypes.sizeof(sctc.TensorInfo), ctypes.sizeof(sctc.BrnnSizes),
+            ctypes.sizeof(sctc.Minibatch), sctc.Minibatch.U_b.offset]
+    assert got == want
+
+
+def test_argument_errors_need_no_gpu(sctc):
+    L = sctc.lib()
+    cfg = sctc.BrnnConfig(20, 6, 30, 3, 2, 10, 1, 20.0, 0.0, 1)
+    sizes = sctc.BrnnSizes()
+    assert L.sctc_brnn_query(ctypes.byref(cfg), ctypes.byref(sizes)) == 0
+    # 20x30 -> [32][32], 30x30 -> [32][32] x2, 30x6 -> [32][32], biases 32 each, Wf, Wb
+    assert sizes.n_tensors == 2 * 4 + 2
+    assert sizes.param_count == 20 * 30 + 30 + 2 * (30 * 30 + 30) + 30 * 6 + 6 + 2 * 30 * 30
+    assert sizes.param_elems == 4 * (32 * 32 + 32) + 2 * 32 * 32
+    assert sizes.workspace_bytes > 0
+    bad = sctc.BrnnConfig(20, 6, 4096, 3, 2, 10, 1, 20.0, 0.0, 1)   # needs 512 resident workgroups
+    assert L.sctc_brnn_query(ctypes.byref(bad), ctypes.byref(sizes)) == -1
+    assert b"workgroups" in L.sctc_last_error()
+    with pytest.raises(ValueError):
+        sctc.check(-1, "x")
+    T = np.array([5], dtype=np.int32)
+    U = np.array([0], dtype=np.int32)
+    off = np.zeros(1, dtype=np.int64)
+    lab = np.zeros(1, dtype=np.int32)
+    bt = sctc.CtcBatch(1, 4, 0, sctc.F64, 4, sctc.i32(T), sctc.i32(U), sctc.i64(off),
+                       sctc.i32(lab), sctc.i64(off), None)
+    assert L.sctc_ctc_workspace_bytes(ctypes.byref(bt)) == 0      # empty label sequence rejected
+    U[0] = 2
+    n = L.sctc_ctc_workspace_bytes(ctypes.byref(bt))
+    assert n >= 2 * 5 * 128 * 8                                   # two float64 lattices of 5 x 128
+
+
+def test_reference_surface_names(sctc):
+    import ctc_fast
+    from nnets import brnnet
+    import cudamat as cm
+    assert callable(ctc_fast.ctc_loss) and callable(ctc_fast.decode_best_path)
+    # ctc_fast.pyx:6 import side effect
+    assert np.geterr()["divide"] == "raise" and np.geterr()["invalid"] == "raise"
+    for name in ("initParams", "paramCount", "setViews", "costAndGrad", "updateParams", "toFile",
+                 "fromFile", "check_grad"):
+        assert callable(getattr(brnnet.NNet, name))
+    for name in ("mult", "add_mult", "euclid_norm", "copy_to_host", "copy_to_device"):
+        assert callable(getattr(cm.CUDAMatrix, name))
+    assert callable(cm.cuda_set_device) and callable(cm.cublas_init)
+    assert cm.padded_layout(1824, 483) == (1824, 512) and cm.padded_layout(33, 1) == (64, 1)
+    assert ctc_fast.collapse_best_path(np.array([0, 3, 3, 0, 3, 1, 4, 4, 8, 5, 0, 5])) == \
+        ([3, 3, 4, 5, 5], [2, 4, 7, 9, 11])
+
+
+def test_no_cpu_fallback(sctc):
+    """without a GPU every compute entry point raises instead of computing on the host"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import ctc_fast
+    from nnets import brnnet
+    y = np.asfortranarray(np.full((3, 4), 1.0 / 3))
+    with pytest.raises(sctc.SctcError):
+        ctc_fast.ctc_loss(y, np.array([1], dtype=np.int32))
+    # argument checking happens before the device is touched, like the Cython signature
+    with pytest.raises(ValueError):
+        ctc_fast.ctc_loss(np.ascontiguousarray(np.full((3, 4), 1.0 / 3)), np.array([1], dtype=np.int32))
+    net = brnnet.NNet(5, 4, 32, 2, 10, temporalLayer=1)
+    with pytest.raises(sctc.SctcError):
+        net.initParams()

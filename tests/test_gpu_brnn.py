@@ -1,0 +1,264 @@
+"""GPU parity of the BRNN step (nnets.brnnet.NNet through the C ABI) against the CPU
+oracle and the golden vectors produced by the reference's rnnetcpu.py -- the re-creation
+of ctc_fast/debug-utils/checkgrads.py:20-40 (GPU fp32 vs CPU fp64, same seed, same init).
+
+Tolerances (fp32 device arithmetic vs fp64 oracle): cost 1e-4 relative (north_star),
+gradients 2e-3 relative Frobenius norm per tensor; observed values are
+one to two orders of magnitude tighter and printed by the diagnostics script.
+"""
+import io
+import pickle
+
+import numpy as np
+import pytest
+
+from tests.helpers import load_net
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import _sctc
+    from nnets import brnnet
+    from oracle import brnn as obrnn
+    return _sctc, brnnet, obrnn, torch
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a, dtype=np.float64) - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def host_stack(params):
+    st = [[w, b] for w, b in zip(params["W"], params["b"])]
+    if params["Wf"] is not None:
+        st += [[params["Wf"], None], [params["Wb"], None]]
+    return st
+
+
+def make_net(brnnet, dims, params, maxUtts=1, reg=0.0, max_act=20.0, train=True, maxBatch=None):
+    D, A, H, NL, TL, T = dims
+    net = brnnet.NNet(D, A, H, NL, maxBatch or T, train=train, temporalLayer=TL, reg=reg,
+                      maxUtts=maxUtts)
+    net.maxAct = max_act
+    net.setParams(host_stack(params))
+    return net
+
+
+def check_grads(net, grads, NL, tol=2e-3):
+    worst = 0.0
+    for i in range(NL + 1):
+        dw, db = net.grad[i]
+        worst = max(worst, rel(dw.copy_to_host(), grads["W"][i]))
+        worst = max(worst, rel(db.copy_to_host().reshape(-1), np.asarray(grads["b"][i]).reshape(-1)))
+    if grads["Wf"] is not None:
+        worst = max(worst, rel(net.grad[NL + 1][0].copy_to_host(), grads["Wf"]))
+        worst = max(worst, rel(net.grad[NL + 2][0].copy_to_host(), grads["Wb"]))
+    assert worst < tol, worst
+    return worst
+
+
+def test_gemm_all_layouts(mods):
+    """sctc_gemm_f32 (== cm.dot) in the four operand layouts, ragged sizes, vs float64 NumPy"""
+    _sctc, _, _, torch = mods
+    L = _sctc.lib()
+    rs = np.random.RandomState(0)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    for (M, N, K) in ((200, 96, 64), (130, 260, 1824), (1000, 1824, 512), (64, 1824, 3000),
+                      (1824, 512, 777), (32, 32, 4)):
+        for akc in (1, 0):
+            for bkc in (1, 0):
+                if (akc and K % 4) or (not akc and M % 4) or (bkc and K % 4) or (not bkc and N % 4):
+                    continue
+                A = rs.randn(M, K).astype(np.float32)
+                Bm = rs.randn(K, N).astype(np.float32)
+                bias = rs.randn(N).astype(np.float32)
+                a_dev = torch.from_numpy(np.ascontiguousarray(A if akc else A.T)).cuda()
+                b_dev = torch.from_numpy(np.ascontiguousarray(Bm.T if bkc else Bm)).cuda()
+                c_dev = torch.full((M, N), 7.0, dtype=torch.float32, device="cuda")
+                bias_dev = torch.from_numpy(bias).cuda()
+                rc = L.sctc_gemm_f32(a_dev.data_ptr(), a_dev.shape[1], akc, b_dev.data_ptr(),
+                                     b_dev.shape[1], bkc, c_dev.data_ptr(), N, M, N, K,
+                                     bias_dev.data_ptr(), 1, ws.data_ptr(), ws.numel(), None)
+                _sctc.check(rc, "gemm")
+                torch.cuda.synchronize()
+                ref = np.maximum(A.astype(np.float64) @ Bm.astype(np.float64) + bias, 0.0)
+                err = np.abs(c_dev.cpu().numpy() - ref).max() / np.abs(ref).max()
+                assert err < 2e-6, (M, N, K, akc, bkc, err)
+
+
+def test_brnn_main_fixture(mods, golden):
+    """rnnetcpu.py __main__ (seed 33): COST 12.023458823 and all gradients"""
+    _, brnnet, obrnn, _ = mods
+    params, grads, dims, data, labels, cost = load_net(golden("brnn_main.npz"))
+    net = make_net(brnnet, dims, params)
+    c, g, skip = net.costAndGrad(data, labels)
+    assert not skip
+    assert c == pytest.approx(cost, rel=1e-4)
+    assert c == pytest.approx(12.023458823, rel=1e-4)
+    check_grads(net, grads, dims[3])
+
+
+def test_brnn_init_matches_reference_seed(mods, golden):
+    """same seed -> same init as the reference (checkgrads.py:20-28)"""
+    _, brnnet, _, _ = mods
+    params, _, dims, data, labels, cost = load_net(golden("brnn_main.npz"))
+    D, A, H, NL, TL, T = dims
+    np.random.seed(33)
+    np.random.randn(D, T)
+    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL)
+    net.initParams()
+    for (w, b), ref in zip(net.stack[:NL + 1], params["W"]):
+        np.testing.assert_allclose(w.copy_to_host(), ref.astype(np.float32), rtol=0, atol=0)
+    np.testing.assert_array_equal(net.stack[NL + 1][0].copy_to_host(), params["Wf"].astype(np.float32))
+    np.testing.assert_array_equal(net.stack[NL + 2][0].copy_to_host(), params["Wb"].astype(np.float32))
+    assert net.stack[NL + 1][1].shape == (1, 1) and net.stack[NL + 1][1] is net.stack[NL + 2][1]
+    assert net.paramCount() == sum(int(np.prod(w.shape)) + int(np.prod(b.shape)) for w, b in net.stack)
+    c, _, _ = net.costAndGrad(data, labels)
+    assert c == pytest.approx(cost, rel=1e-4)
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg5"])
+def test_brnn_scaled_configs(mods, golden, name):
+    _, brnnet, _, _ = mods
+    params, grads, dims, data, labels, cost = load_net(golden("brnn_cfg.npz"), name + "_")
+    net = make_net(brnnet, dims, params)
+    c, g, skip = net.costAndGrad(data, labels)
+    assert not skip
+    assert c == pytest.approx(cost, rel=1e-4)
+    check_grads(net, grads, dims[3])
+
+
+def test_brnn_ceiling_reg_and_masks(mods):
+    """clip at maxAct=20, the strict (0,20) mask and L2 reg: only brnnet.py has them"""
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(5)
+    D, A, H, NL, TL, T = 24, 9, 40, 4, 2, 37
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    params["Wf"] *= 1.5
+    params["b"][TL - 1] += 4.0
+    data = 3.0 * rs.randn(D, T)
+    labels = rs.randint(1, A, size=6).astype(np.int32)
+    reg = 0.01
+    c_ref, g_ref, s_ref, _ = obrnn.cost_and_grad(params, data, labels, TL, 20.0, reg)
+    _, cache = obrnn.forward(params, data, TL, 20.0)
+    assert (cache["hF"] >= 20.0).any() and (cache["hB"] >= 20.0).any()
+    net = make_net(brnnet, (D, A, H, NL, TL, T), params, reg=reg)
+    c, g, skip = net.costAndGrad(data, labels)
+    assert not skip and not s_ref
+    assert c == pytest.approx(c_ref, rel=1e-4)
+    assert net.regcost > 0
+    check_grads(net, g_ref, NL)
+
+
+def test_brnn_no_temporal_layer_and_tl_validity(mods):
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(6)
+    D, A, H, NL, T = 17, 11, 33, 2, 25
+    for TL in (-1, 0, 2, 5):                     # all invalid -> plain DNN (brnnet.py:27-30)
+        net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL)
+        assert net.temporalLayer == -1
+    params = obrnn.init_params(D, A, H, NL, -1, rng=rs)
+    data = rs.randn(D, T)
+    labels = rs.randint(1, A, size=4).astype(np.int32)
+    c_ref, g_ref, _, _ = obrnn.cost_and_grad(params, data, labels, -1)
+    net = make_net(brnnet, (D, A, H, NL, -1, T), params)
+    assert len(net.stack) == NL + 1
+    c, g, skip = net.costAndGrad(data, labels)
+    assert c == pytest.approx(c_ref, rel=1e-4)
+    check_grads(net, g_ref, NL)
+
+
+def test_brnn_minibatch_ragged_sum_of_gradients(mods):
+    """B ragged utterances in one call == sum of the oracle's per-utterance gradients;
+    a skipped (infeasible) utterance contributes nothing"""
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(7)
+    D, A, H, NL, TL = 21, 33, 64, 3, 2
+    Ts = [40, 17, 33, 40, 9, 25, 1, 12]
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 6)).astype(np.int32) for T in Ts]
+    labs[4] = np.array([3, 3, 3, 3, 3, 3], dtype=np.int32)      # T=9 < 11 needed -> skip
+    costs_ref, g_ref, skips_ref, n_valid = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+    assert skips_ref[4] and n_valid == len(Ts) - 1
+    net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=len(Ts))
+    costs, g, skips = net.costAndGradBatch(datas, labs)
+    np.testing.assert_array_equal(skips, skips_ref)
+    ok = ~skips_ref
+    np.testing.assert_allclose(costs[ok], costs_ref[ok], rtol=1e-4)
+    check_grads(net, g_ref, NL)
+    # B=1 through the batch entry point is bit-identical to the single-utterance path
+    c1, _, _ = net.costAndGradBatch([datas[0]], [labs[0]])
+    g_batch = net.grad[0][0].copy_to_host().copy()
+    c2, _, _ = net.costAndGrad(datas[0], labs[0])
+    assert c1[0] == c2
+    np.testing.assert_array_equal(g_batch, net.grad[0][0].copy_to_host())
+    # run-to-run reproducibility of the minibatch gradient
+    net.costAndGradBatch(datas, labs)
+    ga = net.grad[1][0].copy_to_host().copy()
+    net.costAndGradBatch(datas, labs)
+    np.testing.assert_array_equal(ga, net.grad[1][0].copy_to_host())
+
+
+def test_brnn_skip_returns_stale_grads(mods):
+    """brnnet.py:185-186: on skip the previous gradients are returned untouched"""
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(8)
+    D, A, H, NL, TL, T = 10, 5, 32, 2, 1, 12
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    net = make_net(brnnet, (D, A, H, NL, TL, T), params)
+    data = rs.randn(D, T)
+    c, g, skip = net.costAndGrad(data, np.array([1, 2], dtype=np.int32))
+    assert not skip
+    before = net.grad[0][0].copy_to_host().copy()
+    c2, g2, skip2 = net.costAndGrad(data[:, :5], np.array([2, 2, 2, 2], dtype=np.int32))
+    assert skip2
+    np.testing.assert_array_equal(before, net.grad[0][0].copy_to_host())
+
+
+def test_brnn_forward_only_and_checkpoint(mods):
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(9)
+    D, A, H, NL, TL, T = 15, 12, 48, 3, 2, 30
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    data = rs.randn(D, T).astype(np.float32)
+    net = make_net(brnnet, (D, A, H, NL, TL, T), params)
+    buf = io.BytesIO()
+    net.toFile(buf)
+    buf.seek(0)
+    stack = pickle.load(buf)                      # reference format: list of [w, b] float32
+    assert len(stack) == NL + 3 and stack[0][0].dtype == np.float32
+    assert stack[0][0].shape == (H, D) and stack[0][1].shape == (H, 1)
+    assert stack[-1][0].shape == (H, H) and stack[-1][1].shape == (1, 1)
+    buf.seek(0)
+    net2 = brnnet.NNet(D, A, H, NL, T, train=False, temporalLayer=TL)
+    net2.fromFile(buf)
+    probs = net2.costAndGrad(data)                # brnnet.py:171-173
+    assert probs.shape == (A, T) and probs.dtype == np.float32
+    logits, _ = obrnn.forward(params, data.astype(np.float64), TL, 20.0)
+    ref = obrnn.softmax_cols(logits)
+    np.testing.assert_allclose(probs, ref, rtol=2e-4, atol=1e-6)
+    with pytest.raises(AssertionError):
+        net2.costAndGrad(np.zeros((D, T + 1), dtype=np.float32))   # "Batch size exceeds max batch"
+
+
+def test_brnn_update_params(mods):
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(10)
+    D, A, H, NL, TL, T = 8, 5, 32, 2, 1, 6
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    net = make_net(brnnet, (D, A, H, NL, TL, T), params)
+    net.costAndGrad(rs.randn(D, T), np.array([1], dtype=np.int32))
+    w0 = net.stack[0][0].copy_to_host().copy()
+    g0 = net.grad[0][0].copy_to_host().copy()
+    net.updateParams(-0.5, net.grad)              # flat fast path
+    np.testing.assert_allclose(net.stack[0][0].copy_to_host(), w0 - 0.5 * g0, rtol=1e-6, atol=1e-7)
+    vel = net.zerosLikeStack()
+    vel[0][0].add_mult(net.grad[0][0], alpha=2.0)
+    vel[0][0].mult(0.25)
+    np.testing.assert_allclose(vel[0][0].copy_to_host(), 0.5 * g0, rtol=1e-6, atol=1e-7)
+    n = net.grad[0][0].euclid_norm()
+    assert n == pytest.approx(np.linalg.norm(g0.astype(np.float64)), rel=1e-6)
