@@ -180,7 +180,7 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
     if (c->train) {
         ctc_bytes = align256(sizeof(CtcUtt) * Bm) + align256(sizeof(int32_t) * F) +
                     align256(sizeof(double) * 2 * Bm) + align256(sizeof(int32_t) * 2 * Bm) +
-                    2 * align256(sizeof(float) * F * CTC_LP_MAX);
+                    2 * align256(sizeof(double) * F * CTC_LP_MAX);
         ctc_ws = ar.take<char>(ctc_bytes);
     }
     // split-K partials: worst case over the weight-gradient GEMMs

@@ -23,7 +23,7 @@ int set_error(int code, const char* fmt, ...)
     return code;
 }
 
-int ctc_make_plan(int B, int A, int blank, const int32_t* T_b, const int32_t* U_b, size_t esz,
+int ctc_make_plan(int B, int A, int blank, const int32_t* T_b, const int32_t* U_b,
                   CtcPlan* plan)
 {
     SCTC_CHECK_ARG(B >= 1, "ctc: empty batch");
@@ -52,7 +52,7 @@ int ctc_make_plan(int B, int A, int blank, const int32_t* T_b, const int32_t* U_
     plan->n_labels = n_labels;
     plan->bytes = align256(sizeof(CtcUtt) * B) + align256(sizeof(int32_t) * n_labels) +
                   align256(sizeof(double) * 2 * B) + align256(sizeof(int32_t) * 2 * B) +
-                  2 * align256(esz * plan->lat_elems);
+                  2 * align256(sizeof(double) * plan->lat_elems);
     return SCTC_OK;
 }
 
@@ -74,8 +74,8 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
     int32_t* d_labels = ar.take<int32_t>(plan.n_labels);
     double* d_ll = ar.take<double>(2 * plan.B);
     int32_t* d_skip2 = ar.take<int32_t>(2 * plan.B);
-    R* d_alpha = ar.take<R>(plan.lat_elems);
-    R* d_beta = ar.take<R>(plan.lat_elems);
+    double* d_alpha = ar.take<double>(plan.lat_elems);
+    double* d_beta = ar.take<double>(plan.lat_elems);
     if (ar.overflow)
         return set_error(SCTC_ERR_WORKSPACE, "ctc: workspace %zu bytes < %zu needed", ws_bytes,
                          ar.used);
@@ -152,9 +152,8 @@ int ctc_run_batch(const sctc_ctc_batch* bt, const void* probs, void* grad, doubl
     SCTC_CHECK_ARG(bt && probs && grad && cost && skip, "ctc: null argument");
     SCTC_CHECK_ARG(bt->dtype == SCTC_F32 || bt->dtype == SCTC_F64, "ctc: bad dtype %d", bt->dtype);
     SCTC_CHECK_ARG(bt->ld >= bt->A, "ctc: ld %lld < A %d", (long long)bt->ld, bt->A);
-    const size_t esz = bt->dtype == SCTC_F32 ? 4 : 8;
     CtcPlan plan;
-    SCTC_TRY(ctc_make_plan(bt->B, bt->A, bt->blank, bt->T_b, bt->U_b, esz, &plan));
+    SCTC_TRY(ctc_make_plan(bt->B, bt->A, bt->blank, bt->T_b, bt->U_b, &plan));
     if (bt->dtype == SCTC_F32)
         return run_ctc<float>(bt, plan, (const float*)probs, (float*)grad, cost, skip, ws,
                               ws_bytes, stream, keep);
@@ -201,8 +200,7 @@ size_t sctc_ctc_workspace_bytes(const sctc_ctc_batch* bt)
 {
     if (!bt) return 0;
     CtcPlan plan;
-    const size_t esz = bt->dtype == SCTC_F32 ? 4 : 8;
-    if (ctc_make_plan(bt->B, bt->A, bt->blank, bt->T_b, bt->U_b, esz, &plan) != SCTC_OK) return 0;
+    if (ctc_make_plan(bt->B, bt->A, bt->blank, bt->T_b, bt->U_b, &plan) != SCTC_OK) return 0;
     return plan.bytes;
 }
 

@@ -13,31 +13,35 @@ struct CtcUtt {
     int64_t lab_off;  // first label in the concatenated label array
 };
 
-template <typename R>
+// RI = type of probs/grad in HBM (float or double).  The lattices and all lattice
+// arithmetic are float64 like the reference (ctc_fast.pyx:8,28-30): a float32 lattice
+// loses utterances with T >> 2U, where the states that survive the end-of-utterance band
+// carry < 1e-38 of a frame's mass (measured: 0.5-6 % cost error).
+template <typename RI>
 struct CtcLatticeArgs {
     const CtcUtt* utts;
-    const R* probs;
+    const RI* probs;
     int64_t ld;
     int32_t A, blank, lp;
     const int32_t* rowbase;  // nullable
     const int32_t* labels;
-    R* alpha;
-    R* beta;
+    double* alpha;
+    double* beta;
     double* ll;      // [2B] llForward / llBackward
     int32_t* skip2;  // [2B]
 };
 
-template <typename R>
+template <typename RI>
 struct CtcGradArgs {
     const CtcUtt* utts;
-    const R* probs;
-    R* grad;
+    const RI* probs;
+    RI* grad;
     int64_t ld;
     int32_t A, blank, lp;
     const int32_t* rowbase;
     const int32_t* labels;
-    const R* alpha;
-    const R* beta;
+    const double* alpha;
+    const double* beta;
     const double* ll;
     const int32_t* skip2;
     double* cost;   // [B]
@@ -45,10 +49,10 @@ struct CtcGradArgs {
 };
 
 int ctc_states_per_lane(int max_L);  // K in {2,4,8,16,32}; 0 if 2U+1 > 2048
-template <typename R>
-int launch_ctc_lattice(const CtcLatticeArgs<R>& a, int B, int K, hipStream_t stream);
-template <typename R>
-int launch_ctc_grad(const CtcGradArgs<R>& a, int B, int max_T, hipStream_t stream);
+template <typename RI>
+int launch_ctc_lattice(const CtcLatticeArgs<RI>& a, int B, int K, hipStream_t stream);
+template <typename RI>
+int launch_ctc_grad(const CtcGradArgs<RI>& a, int B, int max_T, hipStream_t stream);
 int launch_softmax_rows(const float* x, float* y, int64_t rows, int A, int64_t ld,
                         hipStream_t stream);
 int launch_argmax_rows(const void* y, int dtype, int32_t* best, int64_t rows, int A, int64_t ld,
@@ -60,9 +64,9 @@ struct CtcPlan {
     int B = 0, A = 0, blank = 0, K = 0, lp = 0, max_T = 0;
     int64_t lat_elems = 0;  // elements per lattice (alpha or beta)
     int64_t n_labels = 0;
-    size_t bytes = 0;       // workspace bytes for this plan with element size esz
+    size_t bytes = 0;       // workspace bytes for this plan (float64 lattices)
 };
-int ctc_make_plan(int B, int A, int blank, const int32_t* T_b, const int32_t* U_b, size_t esz,
+int ctc_make_plan(int B, int A, int blank, const int32_t* T_b, const int32_t* U_b,
                   CtcPlan* plan);
 
 }  // namespace sctc

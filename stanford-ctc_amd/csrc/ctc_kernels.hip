@@ -144,9 +144,11 @@ __device__ __forceinline__ int64_t frame_row(const CtcUtt& u, const int32_t* row
 }
 
 // K states per lane (even), NA = ceil(A/64) probability registers per frame.
-template <typename R, int K, int NA>
-__global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<R> p)
+// RI: storage type of probs; the recursion itself runs in float64 (see ctc_kernels.h).
+template <typename RI, int K, int NA>
+__global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
 {
+    using R = double;
     static_assert(K % 2 == 0 && K >= 2, "K must be even");
     constexpr int KH = K / 2;
     const int b = blockIdx.x;
@@ -181,17 +183,17 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<R> p)
 #pragma unroll
     for (int jj = 0; jj < KH; ++jj) valid_blk[jj] = (KH * lane + jj) <= U;
 
-    const R* probs = p.probs;
+    const RI* probs = p.probs;
     const int64_t ld = p.ld;
     const int A = p.A;
 
     auto load_frame = [&](int tau, R (&dst)[NA]) {
         const int t = dir ? T - 1 - tau : tau;
-        const R* yr = probs + frame_row(u, p.rowbase, t) * ld;
+        const RI* yr = probs + frame_row(u, p.rowbase, t) * ld;
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int k = lane + 64 * q;
-            dst[q] = k < A ? yr[k] : (R)0;
+            dst[q] = k < A ? (R)yr[k] : (R)0;   // probs.astype(np.float64), brnnet.py:175
         }
     };
     auto gather = [&](const R (&y)[NA], int k) -> R {
@@ -351,9 +353,10 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<R> p)
 
 // ---------------------------------------------------------------- ctc_grad
 
-template <typename R>
-__global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<R> p)
+template <typename RI>
+__global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<RI> p)
 {
+    using R = double;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.y;
     const CtcUtt u = p.utts[b];
@@ -379,11 +382,11 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<R> p)
     const int t = t0 + wave;
     if (t >= T) return;
     const int64_t row = frame_row(u, p.rowbase, t);
-    const R* yr = p.probs + row * p.ld;
-    R* gr = p.grad + row * p.ld;
+    const RI* yr = p.probs + row * p.ld;
+    RI* gr = p.grad + row * p.ld;
     if (skip) {
         // the reference returns its zero-initialised grad (ctc_fast.pyx:31-32,149)
-        for (int k = lane; k < p.A; k += 64) gr[k] = (R)0;
+        for (int k = lane; k < p.A; k += 64) gr[k] = (RI)0;
         return;
     }
     const R* al = p.alpha + u.lat_off + (int64_t)t * LP;
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<R> p)
         if (s < L) {
             v = al[s] * be[L - 1 - s];                // :119
             ab[s] = v;
-            if (v != (R)0) v = v / yr[lab_s[s]];       // :125-126 / :130-131
+            if (v != (R)0) v = v / (R)yr[lab_s[s]];    // :125-126 / :130-131
         } else {
             ab[s] = (R)0;
         }
@@ -419,21 +422,21 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<R> p)
             if (l.z == k) g += v.z;
             if (l.w == k) g += v.w;
         }
-        const R y = yr[k];
+        const R y = (R)yr[k];
         const R tmp = y * Z;                        // :141
-        gr[k] = tmp > (R)0 ? y - g / tmp : y;       // :142-145
+        gr[k] = (RI)(tmp > (R)0 ? y - g / tmp : y); // :142-145 (cast: CUDAMatrix(deltas), brnnet.py:188)
     }
 }
 
 // ---------------------------------------------------------------- launchers
 
-template <typename R, int K>
-static int launch_lattice_k(const CtcLatticeArgs<R>& a, int B, int NA, hipStream_t stream)
+template <typename RI, int K>
+static int launch_lattice_k(const CtcLatticeArgs<RI>& a, int B, int NA, hipStream_t stream)
 {
     dim3 grid(B, 2), block(64);
-    if (NA == 1) hipLaunchKernelGGL((ctc_lattice_kernel<R, K, 1>), grid, block, 0, stream, a);
-    else if (NA == 2) hipLaunchKernelGGL((ctc_lattice_kernel<R, K, 2>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((ctc_lattice_kernel<R, K, 4>), grid, block, 0, stream, a);
+    if (NA == 1) hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 1>), grid, block, 0, stream, a);
+    else if (NA == 2) hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 2>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 4>), grid, block, 0, stream, a);
     SCTC_HIP_TRY(hipGetLastError());
     return SCTC_OK;
 }
@@ -445,9 +448,10 @@ int ctc_states_per_lane(int max_L)
     return 0;
 }
 
-template <typename R>
-int launch_ctc_lattice(const CtcLatticeArgs<R>& a, int B, int K, hipStream_t stream)
+template <typename RI>
+int launch_ctc_lattice(const CtcLatticeArgs<RI>& a, int B, int K, hipStream_t stream)
 {
+    using R = RI;
     const int NA = a.A <= 64 ? 1 : (a.A <= 128 ? 2 : 4);
     switch (K) {
         case 2: return launch_lattice_k<R, 2>(a, B, NA, stream);
@@ -463,7 +467,7 @@ template <typename R>
 int launch_ctc_grad(const CtcGradArgs<R>& a, int B, int max_T, hipStream_t stream)
 {
     dim3 grid((max_T + 3) / 4, B), block(256);
-    size_t smem = (size_t)a.lp * sizeof(int32_t) + 4 * (size_t)a.lp * sizeof(R);
+    size_t smem = (size_t)a.lp * sizeof(int32_t) + 4 * (size_t)a.lp * sizeof(double);
     if (smem > 48 * 1024)
         SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<R>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -185,47 +185,40 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
             bool tile_on[NTW];
 #pragma unroll
             for (int i = 0; i < NTW; ++i) tile_on[i] = (ng + 2 * i) * 16 < nact;
-            // software pipeline: the loads of the next CB chunks are in flight while the
-            // MFMAs of the current CB chunks issue (x comes from L2 / Infinity Cache)
-            constexpr int CB = NTW == 1 ? 8 : (NTW == 2 ? 4 : 2);
-            float4 xc[CB][NTW], xn[CB][NTW];
-            auto fetch = [&](float4 (&dst)[CB][NTW], int cb) {
+            // All x loads of the step are issued before the first MFMA (up to 64 float4 =
+            // 256 VGPRs per lane; one wave per SIMD owns the whole register file): the
+            // exchange buffer comes from a remote L2 / the Infinity Cache with microsecond
+            // latency, so the step time is latency + streaming, not latency per batch.
+            constexpr int XB = 64 / NTW;
+            for (int cb = c_beg; cb < c_end; cb += XB) {
+                float4 x[XB][NTW];
 #pragma unroll
-                for (int u = 0; u < CB; ++u) {
+                for (int u = 0; u < XB; ++u) {
                     const int c = cb + u;
 #pragma unroll
                     for (int i = 0; i < NTW; ++i) {
                         if (c < c_end && tile_on[i])
-                            dst[u][i] = ld_x(xr + ((size_t)c * Bp + ub[i]) * 16 + 4 * kq, sync_mode);
+                            x[u][i] = ld_x(xr + ((size_t)c * Bp + ub[i]) * 16 + 4 * kq, sync_mode);
                         else
-                            dst[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            x[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
-            };
-            fetch(xc, c_beg);
-            for (int cb = c_beg; cb < c_end; cb += CB) {
-                fetch(xn, cb + CB);
 #pragma unroll
-                for (int u = 0; u < CB; ++u) {
+                for (int u = 0; u < XB; ++u) {
                     const int c = cb + u;
                     if (c < c_end) {
                         const float4 a = Wl[c * 64 + lane];
 #pragma unroll
                         for (int i = 0; i < NTW; ++i) {
                             if (tile_on[i]) {
-                                const float4 x = xc[u][i];
-                                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x.x, acc[i][0], 0, 0, 0);
-                                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x.y, acc[i][1], 0, 0, 0);
-                                acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x.z, acc[i][2], 0, 0, 0);
-                                acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x.w, acc[i][3], 0, 0, 0);
+                                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[u][i].x, acc[i][0], 0, 0, 0);
+                                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[u][i].y, acc[i][1], 0, 0, 0);
+                                acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[u][i].z, acc[i][2], 0, 0, 0);
+                                acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[u][i].w, acc[i][3], 0, 0, 0);
                             }
                         }
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < CB; ++u)
-#pragma unroll
-                    for (int i = 0; i < NTW; ++i) xc[u][i] = xn[u][i];
             }
             // fold the two K halves: upper half parks its partials in LDS
             if (kh == 1) {
