@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio frames/sec of one full costAndGrad (BRNN forward + softmax/CTC
++ BRNN backward, weight gradients resident on the device; data-parallel: after the RCCL
+all-reduce) at the WSJ shape of BASELINE.json configs[2]:
+T=1000, |alphabet|=33, 5x1824 BRNN (temporalLayer 3, inputDim 483), U=100, minibatch 32 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0.  Synthetic features/labels (SURVEY 8(d) generators), reference
+weight init, fp32 arithmetic like the reference's cudamat path.  Weak scaling: every GPU
+processes its own 32 utterances; the only exchange is the sum of the weight gradients.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "stanford-ctc_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+# cfg-3 of SURVEY 8(d)
+CFG = dict(D=483, A=33, H=1824, NL=5, TL=3, T=1000, U=100, B=32)
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32 matrix peak
+PEAK_HBM_GBPS = 8000.0
+PHASES = ["fwd_gemm", "fwd_rec", "ctc", "bwd_gemm", "bwd_rec", "other"]
+
+
+def cpu_baseline(cfg, budget_s=20.0, max_utts=12):
+    """The oracle (NumPy float64 BRNN restatement of rnnetcpu.py + C restatement of
+    ctc_fast.pyx) timed on the host cores for a bounded sample of the same workload:
+    whole utterances of the cfg-3 shape, one at a time like the reference's SGD loop."""
+    from oracle import brnn as obrnn
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    rs = np.random.RandomState(0)
+    params = obrnn.init_params(cfg["D"], cfg["A"], cfg["H"], cfg["NL"], cfg["TL"], rng=rs)
+    n, t_total = 0, 0.0
+    with np.errstate(all="ignore"):
+        while n < max_utts and (n == 0 or t_total + t_total / n < budget_s):
+            data = rs.randn(cfg["D"], cfg["T"])
+            labels = rs.randint(1, cfg["A"], size=cfg["U"]).astype(np.int32)
+            t0 = time.time()
+            obrnn.cost_and_grad(params, data, labels, cfg["TL"], max_act=20.0)
+            t_total += time.time() - t0
+            n += 1
+    return {"value": n * cfg["T"] / t_total, "unit": "frames/s", "cores": int(threads),
+            "kind": "port",
+            "sample": "%d utterances of T=%d (cfg-3 shape), %.1f s, NumPy f64 BRNN oracle + C CTC "
+                      "oracle, BLAS threads=%d of %d host cores" % (n, cfg["T"], t_total, threads,
+                                                                    os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=CFG["B"], help="utterances per GPU")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    import _sctc
+    from nnets import brnnet
+    import dist_sgd
+
+    cfg = dict(CFG)
+    cfg["B"] = args.batch
+    D, A, H, NL, TL, T, U, B = (cfg[k] for k in ("D", "A", "H", "NL", "TL", "T", "U", "B"))
+    np.random.seed(0)                       # identical initial weights on every rank
+    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B)
+    net.initParams()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    feats = torch.randn(B * T, D, device="cuda", generator=gen)     # resident in HBM
+    rs = np.random.RandomState(100 + rank)
+    labels = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
+    Ts = [T] * B
+    dp = dist_sgd.DataParallel(net) if world > 1 else None
+
+    def step():
+        cost, grad, skip = net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+        if dp is not None:
+            dp.allreduce_gradients(n_valid_local=int((~skip).sum()))
+        return cost, skip
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cost, skip = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames_total = world * B * T * args.steps
+    ms_per_step = elapsed / args.steps * 1e3
+
+    out = None
+    if rank == 0:
+        # ---- roofline leg: hipEvent phase timers on the compute stream (extra syncs, untimed)
+        L = _sctc.lib()
+        L.sctc_brnn_set_profiling(net._h, 1)
+        acc = np.zeros(len(PHASES))
+        reps = 3
+        arr = (ctypes.c_float * len(PHASES))()
+        for _ in range(reps):
+            net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+            L.sctc_brnn_phase_ms(net._h, arr)
+            acc += np.array(list(arr))
+        L.sctc_brnn_set_profiling(net._h, 0)
+        acc /= reps
+        ph = dict(zip(PHASES, [float(v) for v in acc]))
+        tot, gm, rc = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        mb, keep = net._minibatch(feats, Ts, labels)
+        L.sctc_brnn_flops(net._h, ctypes.byref(mb), ctypes.byref(tot), ctypes.byref(gm),
+                          ctypes.byref(rc))
+        gemm_ms = ph["fwd_gemm"] + ph["bwd_gemm"]
+        rec_ms = ph["fwd_rec"] + ph["bwd_rec"]
+        n_gemm_launches = (NL + 1) + (NL + 1) + NL + 2
+        achieved = gm.value / (gemm_ms * 1e-3) / 1e12
+        ctc_bytes = B * (2 * 4 * A * T + 4 * U + 8)
+        out = {
+            "metric": "audio frames/sec (CTC fwd-bwd + BRNN grad) at T=1000, L=5, H=1824, |Sigma|=33",
+            "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "WSJ-shape cfg-3: T=1000 A=33 5x1824 BRNN (temporalLayer 3, "
+                                   "inputDim 483) U=100, minibatch %d per GPU, one costAndGrad per "
+                                   "step" % B,
+                       "utterances_per_gpu": B, "frames_per_step": world * B * T,
+                       "parallelism": "dp%d" % world if world > 1 else "single-gpu"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (all time-batched GEMMs)",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "launches_per_step": n_gemm_launches,
+                         "avg_launch_ms": gemm_ms / n_gemm_launches,
+                         "algorithmic_tflop_per_step": gm.value / 1e12},
+            "roofline_recurrent": {"bound": "mfma", "kernel": "brnn_recurrent_kernel",
+                                   "achieved": rc.value / (rec_ms * 1e-3) / 1e12,
+                                   "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": rc.value / (rec_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                   "avg_launch_ms": rec_ms / 2, "us_per_time_step": rec_ms * 1e3 / (2 * (T - 1))},
+            "roofline_ctc": {"bound": "hbm", "kernel": "softmax_rows + ctc_lattice + ctc_grad",
+                             "achieved": ctc_bytes / (ph["ctc"] * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS,
+                             "unit": "GB/s", "frac": ctc_bytes / (ph["ctc"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                             "algorithmic_bytes": ctc_bytes, "ms": ph["ctc"]},
+            "phase_ms": ph,
+            "cost_mean": float(np.mean(cost[~skip])) if (~skip).any() else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -393,6 +393,7 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
             r.counters = h->counters;
             r.sync_mode = h->rec_sync_mode;
             SCTC_TRY(launch_recurrent(r, s));
+            pt.begin(SCTC_PHASE_OTHER);
             // hActs[i] = hActsFor + hActsBack, brnnet.py:153
             SCTC_TRY(launch_add(h->act[i], h->hF, h->hB, N * h->Hp, s));
         }
@@ -505,9 +506,11 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             SCTC_TRY(launch_gemm_f32(g, s));
         }
         // db = deltasIn.sum(axis=1), brnnet.py:200
+        pt.begin(SCTC_PHASE_OTHER);
         SCTC_TRY(launch_colsum(d_in, d_in_ld, N, outp,
                                h->grads + h->tinfo[bias_index(h, i)].offset, acc, h->colsum_ws, s));
         if (i == 0) break;
+        pt.begin(SCTC_PHASE_BWD_GEMM);
         // deltasOut = W^T deltasIn, brnnet.py:204  (+ sign(hActs[i]) mask, :235-237)
         float* d_out = bufs[which];
         {
@@ -586,6 +589,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
                 SCTC_TRY(launch_gemm_f32(g, s));
             }
             // deltasOut = deltasFor + deltasBack, brnnet.py:233
+            pt.begin(SCTC_PHASE_OTHER);
             SCTC_TRY(launch_add(d_out, h->dF, h->dBk, N * h->Hp, s));
         }
         d_in = d_out;
@@ -604,6 +608,7 @@ static int run_cost_and_grad(sctc_brnn* h, const sctc_minibatch* mb, int flags, 
     SCTC_TRY(make_plan(h, mb, true, s));
     SCTC_TRY(run_forward(h, mb, s, pt));
     SCTC_TRY(run_ctc(h, mb, s));
+    pt.begin(SCTC_PHASE_OTHER);
     hipLaunchKernelGGL(unpermute_results_kernel, dim3((h->B + 63) / 64), dim3(64), 0, s, h->d_cost,
                        h->d_skip, h->d_perm, h->B, h->d_cost_out, h->d_skip_out);
     *all_skipped = false;

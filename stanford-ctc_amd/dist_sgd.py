@@ -1,0 +1,79 @@
+"""Data-parallel minibatch training across the GPUs of one node.
+
+The reference has no multi-GPU path at all (one process = one GPU picked by CUDA_DEVICE,
+runNNet.py:117-120; "distributed" = ssh-launched independent jobs, cluster/utils.py:112-128).
+The only reference behaviour to match is the minibatch-mean convention of ctc/nnet.py:106-124:
+the update uses the mean gradient over the non-skipped utterances.
+
+Design (one process per GPU, torch.distributed; backend "nccl" IS RCCL on ROCm):
+  * utterances shard by length-balanced round-robin (independent units, no data-path
+    collective);
+  * each rank runs the batched costAndGrad over its shard -> SUM of its utterances'
+    gradients in one flat fp32 buffer (the engine's padded parameter layout);
+  * ONE exchange step: all-reduce(sum) of the flat gradient buffer in a few large buckets
+    (84 MB at cfg-3; xGMI is point-to-point, 7 links x ~153 GB/s per GPU, so few large
+    messages beat many small ones) plus a 2-float side message [n_valid, cost_sum];
+  * every rank applies the identical update with grad_scale = 1/n_valid_global, so weights
+    stay bit-identical without any broadcast after initialisation.
+"""
+import numpy as np
+
+DEFAULT_BUCKET_ELEMS = 16 * 1024 * 1024     # 64 MB of fp32 per all-reduce call
+
+
+def shard_utterances(lengths, world, rank):
+    """indices of the utterances rank `rank` processes: longest first, each utterance dealt to
+    the rank with the fewest frames so far (ties: lowest rank) -- balances sum(T) per rank
+    (SURVEY 8(e) "Partitioning"); deterministic, so every rank computes the same partition."""
+    lengths = np.asarray(lengths)
+    order = np.argsort(-lengths, kind="stable")
+    load = [0] * world
+    shards = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        shards[r].append(int(i))
+        load[r] += int(lengths[i])
+    return shards[rank]
+
+
+def allreduce_flat(flat, side, bucket_elems=DEFAULT_BUCKET_ELEMS, group=None):
+    """Sum-all-reduce the 1-D tensor `flat` in place, bucket by bucket, and the small 1-D
+    float64 tensor `side` (e.g. [n_valid, cost_sum]).  Works for CUDA (RCCL) and CPU (gloo)
+    tensors; asynchronous bucket handles are waited for at the end so that the copies of
+    consecutive buckets overlap on the wire."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return flat, side
+    handles = []
+    n = flat.numel()
+    for start in range(0, n, bucket_elems):
+        handles.append(dist.all_reduce(flat[start:min(n, start + bucket_elems)],
+                                       op=dist.ReduceOp.SUM, group=group, async_op=True))
+    handles.append(dist.all_reduce(side, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for h in handles:
+        h.wait()
+    return flat, side
+
+
+class DataParallel(object):
+    """Wraps an nnets.brnnet.NNet whose gradient stack lives in one flat device buffer."""
+
+    def __init__(self, net, bucket_elems=DEFAULT_BUCKET_ELEMS, group=None):
+        self.net = net
+        self.bucket_elems = bucket_elems
+        self.group = group
+        self.n_valid = 0
+        self.cost_sum = 0.0
+
+    def allreduce_gradients(self, n_valid_local, cost_sum_local=0.0):
+        """after net.costAndGradBatch on every rank: sums gradients, utterance counts and costs
+        over the ranks.  Returns grad_scale = 1/n_valid_global (0 if every utterance skipped)."""
+        import torch
+        flat = self.net.grad.flat
+        side = torch.tensor([float(n_valid_local), float(cost_sum_local)], dtype=torch.float64,
+                            device=flat.device)
+        allreduce_flat(flat, side, self.bucket_elems, self.group)
+        side = side.cpu()
+        self.n_valid = int(round(side[0].item()))
+        self.cost_sum = float(side[1].item())
+        return 1.0 / self.n_valid if self.n_valid > 0 else 0.0
