@@ -182,6 +182,8 @@ int sctc_brnn_forward(sctc_brnn_t h, const sctc_minibatch* mb, float* probs_dev,
 #define SCTC_PHASE_OTHER 5
 #define SCTC_N_PHASES 6
 int sctc_brnn_set_profiling(sctc_brnn_t h, int32_t enable);
+/* diagnostics only: per-step s_memtime stamps of the recurrent kernel when SCTC_REC_DEBUG=1 */
+int sctc_brnn_debug_read(sctc_brnn_t h, uint32_t* out, int32_t n_words);
 int sctc_brnn_phase_ms(sctc_brnn_t h, float* ms_out /* [SCTC_N_PHASES] */);
 /* algorithmic FLOPs of one cost_and_grad over this minibatch, SURVEY 8(d) formula
  * (total, and the part in the time-batched GEMMs / in the recurrent steps) */

@@ -47,7 +47,7 @@ struct sctc_brnn {
     float *Z, *hF, *hB;       // temporal layer: pre-activation, forward / backward states
     float *logits, *probs, *dlogits;
     float *dA, *dBuf, *dF, *dBk;  // deltas: ping-pong pair + recurrent pair
-    int32_t *d_rowbase, *d_nact, *d_Ts, *d_src_row, *d_idx_lo, *d_idx_hi;
+    int32_t *d_rowbase, *d_nact, *d_Ts, *d_src_row, *d_idx_lo, *d_idx_hi, *d_xbase;
     void* ctc_ws;
     size_t ctc_ws_bytes;
     float* splitk_ws;
@@ -55,6 +55,8 @@ struct sctc_brnn {
     float* colsum_ws;
     float* xbuf;
     unsigned* counters;
+    unsigned* rec_debug = nullptr;  // [2 passes][REC_DEBUG_WORDS] step timestamps (SCTC_REC_DEBUG=1)
+    int rec_debug_on = 0;
     double* d_cost;   // [maxB] sorted order
     int32_t* d_skip;  // [maxB]
     double* d_cost_out;  // [maxB] caller order
@@ -64,7 +66,8 @@ struct sctc_brnn {
     int32_t* d_perm;  // [maxB] rank -> caller index
 
     // per-call plan (host)
-    std::vector<int32_t> order, Ts, rowbase, nact, src_row, idx_lo, idx_hi;
+    std::vector<int32_t> order, Ts, rowbase, nact, src_row, idx_lo, idx_hi, xbase;
+    int64_t n_xrows = 0;
     int64_t N = 0;
     int B = 0, Tmax = 0;
     int64_t npairs = 0;
@@ -173,6 +176,7 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
     int32_t* d_src_row = ar.take<int32_t>(F);
     int32_t* d_idx_lo = ar.take<int32_t>(F);
     int32_t* d_idx_hi = ar.take<int32_t>(F);
+    int32_t* d_xbase = ar.take<int32_t>(F);
     int32_t* d_perm = ar.take<int32_t>(Bm);
     // CTC workspace, worst case: every frame carries a CTC_LP_MAX-wide lattice row (x2)
     size_t ctc_bytes = 0;
@@ -198,8 +202,9 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
     }
     float* splitk_ws = sk ? f(sk) : nullptr;
     float* colsum_ws = c->train ? f(colsum_ws_floats(F, std::max(d.Hp, d.Ap))) : nullptr;
-    float* xbuf = d.TL > 0 ? f((int64_t)recurrent_xbuf_floats(d.Hp, Bm)) : nullptr;
-    unsigned* counters = ar.take<unsigned>(64);
+    float* xbuf = d.TL > 0 ? f((int64_t)recurrent_xbuf_floats(d.Hp, recurrent_xrows_bound(F, F))) : nullptr;
+    unsigned* counters = ar.take<unsigned>(REC_COUNTER_WORDS);
+    unsigned* rec_debug = ar.take<unsigned>(2 * REC_DEBUG_WORDS);
     double* d_cost = ar.take<double>(Bm);
     int32_t* d_skip = ar.take<int32_t>(Bm);
     double* d_cost_out = ar.take<double>(Bm);
@@ -211,10 +216,10 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
         h->logits = logits; h->probs = probs; h->dlogits = dlogits;
         h->dA = dA; h->dBuf = dBuf; h->dF = dF; h->dBk = dBk;
         h->d_rowbase = d_rowbase; h->d_nact = d_nact; h->d_Ts = d_Ts; h->d_src_row = d_src_row;
-        h->d_idx_lo = d_idx_lo; h->d_idx_hi = d_idx_hi; h->d_perm = d_perm;
+        h->d_idx_lo = d_idx_lo; h->d_idx_hi = d_idx_hi; h->d_perm = d_perm; h->d_xbase = d_xbase;
         h->ctc_ws = ctc_ws; h->ctc_ws_bytes = ctc_bytes;
         h->splitk_ws = splitk_ws; h->splitk_floats = sk; h->colsum_ws = colsum_ws;
-        h->xbuf = xbuf; h->counters = counters;
+        h->xbuf = xbuf; h->counters = counters; h->rec_debug = rec_debug;
         h->d_cost = d_cost; h->d_skip = d_skip; h->d_cost_out = d_cost_out;
         h->d_skip_out = d_skip_out; h->d_sumsq = d_sumsq; h->sumsq_ws = sumsq_ws;
     }
@@ -255,15 +260,19 @@ static int make_plan(sctc_brnn* h, const sctc_minibatch* mb, bool need_labels, h
     h->Tmax = Tmax;
     h->rowbase.assign(Tmax, 0);
     h->nact.assign(Tmax, 0);
+    h->xbase.assign(Tmax, 0);
     {
         int na = B;
-        int64_t base = 0;
+        int64_t base = 0, xb = 0;
         for (int t = 0; t < Tmax; ++t) {
             while (na > 0 && h->Ts[na - 1] <= t) --na;
             h->nact[t] = na;
             h->rowbase[t] = (int32_t)base;
+            h->xbase[t] = (int32_t)xb;     // exchange rows: every step's block starts on 256 B
             base += na;
+            xb += (na + 3) & ~3;
         }
+        h->n_xrows = xb;
     }
     h->src_row.resize(N);
     h->idx_lo.clear();
@@ -281,6 +290,8 @@ static int make_plan(sctc_brnn* h, const sctc_minibatch* mb, bool need_labels, h
     SCTC_HIP_TRY(hipMemcpyAsync(h->d_rowbase, h->rowbase.data(), sizeof(int32_t) * Tmax,
                                 hipMemcpyHostToDevice, stream));
     SCTC_HIP_TRY(hipMemcpyAsync(h->d_nact, h->nact.data(), sizeof(int32_t) * Tmax,
+                                hipMemcpyHostToDevice, stream));
+    SCTC_HIP_TRY(hipMemcpyAsync(h->d_xbase, h->xbase.data(), sizeof(int32_t) * Tmax,
                                 hipMemcpyHostToDevice, stream));
     SCTC_HIP_TRY(hipMemcpyAsync(h->d_Ts, h->Ts.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice,
                                 stream));
@@ -383,15 +394,16 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
             r.ld = h->Hp;
             r.Hp = h->Hp;
             r.B = h->B;
-            r.Bp = (int)round_up(h->B, 16);
             r.Tmax = h->Tmax;
             r.rowbase = h->d_rowbase;
-            r.nact = h->d_nact;
             r.T_b = h->d_Ts;
             r.max_act = h->cfg.max_act;
             r.xbuf = h->xbuf;
+            r.xbase = h->d_xbase;
+            r.n_xrows = (int)h->n_xrows;
             r.counters = h->counters;
             r.sync_mode = h->rec_sync_mode;
+            r.debug = h->rec_debug_on ? h->rec_debug : nullptr;
             SCTC_TRY(launch_recurrent(r, s));
             pt.begin(SCTC_PHASE_OTHER);
             // hActs[i] = hActsFor + hActsBack, brnnet.py:153
@@ -547,15 +559,16 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             r.ld = h->Hp;
             r.Hp = h->Hp;
             r.B = h->B;
-            r.Bp = (int)round_up(h->B, 16);
             r.Tmax = h->Tmax;
             r.rowbase = h->d_rowbase;
-            r.nact = h->d_nact;
             r.T_b = h->d_Ts;
             r.max_act = h->cfg.max_act;
             r.xbuf = h->xbuf;
+            r.xbase = h->d_xbase;
+            r.n_xrows = (int)h->n_xrows;
             r.counters = h->counters;
             r.sync_mode = h->rec_sync_mode;
+            r.debug = h->rec_debug_on ? h->rec_debug + REC_DEBUG_WORDS : nullptr;
             SCTC_TRY(launch_recurrent(r, s));
             pt.begin(SCTC_PHASE_BWD_GEMM);
             // dwtf = deltasFor[:,1:T] . hActsFor[:,0:T-1]^T ; dwtb = deltasBack[:,0:T-1] . hActsBack[:,1:T]^T
@@ -673,7 +686,9 @@ int sctc_brnn_create(const sctc_brnn_config* cfg, float* params_dev, float* grad
         return set_error(SCTC_ERR_HIP, "brnn_create: %s", hipGetErrorString(e));
     }
     const char* sm = getenv("SCTC_REC_SYNC");
-    h->rec_sync_mode = sm ? atoi(sm) : 0;
+    h->rec_sync_mode = sm ? atoi(sm) : 1;
+    const char* dbg = getenv("SCTC_REC_DEBUG");
+    h->rec_debug_on = dbg ? atoi(dbg) : 0;
     *out = h;
     return SCTC_OK;
 }
@@ -764,6 +779,14 @@ int sctc_brnn_forward(sctc_brnn_t h, const sctc_minibatch* mb, float* probs_dev,
     SCTC_TRY(launch_scatter_rows(probs_dev, h->A, h->probs, h->Ap, h->d_src_row, h->N, h->A, s));
     pt.end();
     return check_recurrent_error(h, s);
+}
+
+/* diagnostics: s_memtime stamps of the recurrent kernel (SCTC_REC_DEBUG=1), [2 passes][2 wgs][16 steps][8] */
+int sctc_brnn_debug_read(sctc_brnn_t h, uint32_t* out, int32_t n_words)
+{
+    SCTC_CHECK_ARG(h && out && n_words >= 0 && n_words <= 2 * REC_DEBUG_WORDS, "debug_read: bad argument");
+    SCTC_HIP_TRY(hipMemcpy(out, h->rec_debug, sizeof(uint32_t) * n_words, hipMemcpyDeviceToHost));
+    return SCTC_OK;
 }
 
 int sctc_brnn_set_profiling(sctc_brnn_t h, int32_t enable)

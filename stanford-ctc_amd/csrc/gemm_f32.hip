@@ -202,12 +202,20 @@ int64_t gemm_plan_splits(int M, int N, int K, int* splits)
     const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
     const int ktiles = (K + BK - 1) / BK;
     int s = 1;
-    // fewer tiles than ~2 per CU: split K until the grid fills the 256 CUs twice
-    if (mt * nt < 256) {
-        s = (512 + mt * nt - 1) / (mt * nt);
-        s = std::min(s, std::max(1, ktiles / 8));  // keep >= 8 K tiles per split
-        s = std::min(s, 64);
-        s = std::max(s, 1);
+    // 256 CUs x 2 resident blocks = 512 slots.  A grid that is not a multiple of that leaves a
+    // partial last round (225 tiles x 3 splits = 675 blocks ran at 66 %); pick the split that
+    // fills whole rounds best, keeping >= 8 K tiles per split.
+    const int tiles = mt * nt, slots = 512;
+    if (tiles < 2 * slots) {
+        double best = 0.0;
+        const int smax = std::min(64, std::max(1, ktiles / 8));
+        for (int c = 1; c <= smax; ++c) {
+            const int blocks = tiles * c;
+            const int rounds = (blocks + slots - 1) / slots;
+            // efficiency of the last round, mildly penalising the extra partial traffic
+            const double eff = (double)blocks / ((double)rounds * slots) - 0.002 * c;
+            if (eff > best + 1e-9) { best = eff; s = c; }
+        }
     }
     *splits = s;
     return s > 1 ? (int64_t)s * M * N : 0;

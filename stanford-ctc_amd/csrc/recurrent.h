@@ -23,19 +23,27 @@ struct RecArgs {
     int64_t ld;
     int32_t Hp;             // padded layer size (multiple of 32)
     int32_t B;              // utterances
-    int32_t Bp;             // B rounded up to 16
     int32_t Tmax;
     const int32_t* rowbase; // device [Tmax]
-    const int32_t* nact;    // device [Tmax] utterances still running at step j
     const int32_t* T_b;     // device [B] (sorted, descending)
     float max_act;          // <= 0: no ceiling
-    float* xbuf;            // exchange buffers [2 groups][2 parity][Hp/16][Bp][16]
-    unsigned* counters;     // [2] arrival counters (zeroed by the launcher) + [1] error word
-    int32_t sync_mode;      // 0: plain stores/loads + agent release/acquire fences
-                            // 1: write-through (sc1) 8-byte atomics both sides, no fences
+    // Exchange buffer: chunk-major copy of the state, [2 groups][Hp/16][n_xrows][16] floats.
+    // Exchange row of utterance b at STEP j = xbase[j] + b; xbase rounds every step's
+    // block up to 4 rows (256 B) so that no cache line holds data of two different steps.
+    float* xbuf;
+    const int32_t* xbase;   // device [Tmax]
+    int32_t n_xrows;
+    unsigned* counters;     // [REC_COUNTER_WORDS]: error word at [2], per-producer step flags at [4..260)
+    int32_t sync_mode;      // 0: plain exchange stores + agent-scope release fence before the flag
+                            // 1: write-through (sc1) exchange stores, no fence
+    unsigned* debug;        // nullable: s_memtime stamps [2 wgs][16 steps][8] for steps 64..79
 };
+static constexpr int REC_DEBUG_WORDS = 2 * 16 * 8;
+static constexpr int REC_COUNTER_WORDS = 4 + 256;
 
-size_t recurrent_xbuf_floats(int Hp, int B);
+// exchange rows needed for `rows` frames spread over `tmax` time steps (worst case)
+static inline int64_t recurrent_xrows_bound(int64_t rows, int64_t tmax) { return rows + 3 * tmax; }
+size_t recurrent_xbuf_floats(int Hp, int64_t max_xrows);
 int recurrent_supported(int Hp, int B, char* why, int why_len);
 int launch_recurrent(const RecArgs& a, hipStream_t stream);
 

@@ -9,12 +9,25 @@
 // time step is a (16 x H) . (H x B) product per workgroup, split over the 4 waves
 // as 2 K-halves x 2 utterance groups and reduced through LDS.  A step's result
 // is published twice: into the [rows][H] activation matrix used by the
-// time-batched GEMMs, and into a small exchange buffer laid out
-// [16-unit chunk][utterance][16] -- chunk c is written by workgroup c as one
-// contiguous block and read by every workgroup as 1 KiB-per-wave coalesced
-// loads that land directly in MFMA B-fragment order.
-// Steps are separated by a grid barrier per direction (monotonic arrival counter,
-// agent-scope release/acquire as MI355X_MICROARCH prescribes; every spin bounded).
+// time-batched GEMMs, and into the exchange buffer, a chunk-major copy
+// [16-unit chunk][exchange row][16]: chunk c is written only by workgroup c, a
+// step's rows form one contiguous 256-byte-aligned block per chunk, and readers
+// fetch them as 16-byte-per-lane loads that land directly in MFMA B-fragment
+// order.  All loads of a step are issued before its first MFMA (one wave per
+// SIMD owns the whole register file).
+//
+// Step synchronisation (per direction): an all-gather of per-producer step flags.
+// Producer: exchange stores -> s_waitcnt vmcnt(0) per wave -> workgroup barrier ->
+// one lane publishes flag[wg] = step+1.  Consumer: one wave polls all H/16 flags
+// (relaxed agent-scope loads, two per lane) until every producer has arrived, then
+// reads with plain cacheable loads.  Every exchange address is written exactly once
+// per launch and its cache line holds data of one step only, so neither a CU's L1 nor
+// an XCD's L2 can hold a stale copy: no acquire invalidate is needed and the 14
+// same-XCD readers of a line share one fabric fetch.
+//   sync_mode 0: plain payload stores + agent-scope release fence before the flag;
+//   sync_mode 1: write-through (sc1) payload stores, no fence.
+// Every spin is bounded (3 s) and raises an error word the host turns into
+// SCTC_ERR_TIMEOUT; flags are zeroed by a memset node before each launch.
 //
 // The K index inside a 16-chunk is permuted (k = 16c + 4*(lane>>4) + q for MFMA q)
 // identically for W and x, so both operands are 16-byte vector loads.
@@ -24,42 +37,31 @@
 namespace sctc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr unsigned long long SPIN_TIMEOUT_TICKS = 300000000ull;  // 3 s of the 100 MHz clock
 
-__device__ __forceinline__ float4 ld_x(const float* p, int sync_mode)
+__device__ __forceinline__ float4 ld_x(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off,
+                                       unsigned chunk_off)
 {
-    if (sync_mode == 1) {
-        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-        unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        float4 r;
-        r.x = __uint_as_float((unsigned)lo);
-        r.y = __uint_as_float((unsigned)(lo >> 32));
-        r.z = __uint_as_float((unsigned)hi);
-        r.w = __uint_as_float((unsigned)(hi >> 32));
-        return r;
-    }
-    return *reinterpret_cast<const float4*>(p);
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, chunk_off, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
+                       __uint_as_float(v[3]));
 }
 
-__device__ __forceinline__ void st_x(float* p, float4 v, int sync_mode)
+__device__ __forceinline__ void st_x(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off,
+                                     unsigned chunk_off, float4 v, int sync_mode)
 {
-    if (sync_mode == 1) {
-        unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-        unsigned long long lo = (unsigned long long)__float_as_uint(v.x) |
-                                ((unsigned long long)__float_as_uint(v.y) << 32);
-        unsigned long long hi = (unsigned long long)__float_as_uint(v.z) |
-                                ((unsigned long long)__float_as_uint(v.w) << 32);
-        __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    *reinterpret_cast<float4*>(p) = v;
+    u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z),
+               __float_as_uint(v.w)};
+    if (sync_mode == 1)
+        __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, lane_off, chunk_off, 16 /* sc1 */);
+    else
+        __builtin_amdgcn_raw_buffer_store_b128(u, rsrc, lane_off, chunk_off, 0);
 }
 
-// all threads call; publishes this workgroup's stores of the step
-__device__ __forceinline__ void grid_arrive(unsigned* ctr, int sync_mode)
+// all threads call; publishes this workgroup's stores of the step as flag[wg] = value
+__device__ __forceinline__ void publish_step(unsigned* flag, unsigned value, int sync_mode)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
     __syncthreads();
@@ -68,43 +70,62 @@ __device__ __forceinline__ void grid_arrive(unsigned* ctr, int sync_mode)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // keep the wait behind buffer_wbl2
         }
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// all threads call; returns after every workgroup of the group has arrived `target` times
-__device__ __forceinline__ void grid_wait(unsigned* ctr, unsigned target, unsigned* err,
-                                          int sync_mode)
+// all threads call; returns once every one of the `nwg` producers has published >= target
+__device__ __forceinline__ void wait_all(unsigned* flags, int nwg, unsigned target, unsigned* err)
 {
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
         const unsigned long long t0 = wall_clock64();
         unsigned spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        for (;;) {
+            unsigned f0 = target, f1 = target;
+            if (lane < nwg)
+                f0 = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane + 64 < nwg)
+                f1 = __hip_atomic_load(flags + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(f0 >= target && f1 >= target)) break;
             __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 1023u) == 0) {
-                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                if (wall_clock64() - t0 > SPIN_TIMEOUT_TICKS) {
-                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+            if ((++spins & 255u) == 0) {
+                bool give_up = false;
+                if (lane == 0) {
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                        give_up = true;
+                    else if (wall_clock64() - t0 > SPIN_TIMEOUT_TICKS) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        give_up = true;
+                    }
                 }
+                if (__any(give_up)) break;
             }
         }
-        if (sync_mode == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
 }
 
-template <int NTW>
+#define SCTC_MFMA4(ACC, A, X)                                                                 \
+    ACC[0] = __builtin_amdgcn_mfma_f32_16x16x4f32((A).x, (X).x, ACC[0], 0, 0, 0);             \
+    ACC[1] = __builtin_amdgcn_mfma_f32_16x16x4f32((A).y, (X).y, ACC[1], 0, 0, 0);             \
+    ACC[2] = __builtin_amdgcn_mfma_f32_16x16x4f32((A).z, (X).z, ACC[2], 0, 0, 0);             \
+    ACC[3] = __builtin_amdgcn_mfma_f32_16x16x4f32((A).w, (X).w, ACC[3], 0, 0, 0);
+
+// NTW: utterance tiles (16 each) per wave.  NCHH: 16-unit K chunks per wave when known at
+// compile time (Hp == 32*NCHH: fully unrolled, branch-free), 0 = run-time loop.
+template <int NTW, int NCHH>
 __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
     const int g = blockIdx.x & 1, wg = blockIdx.x >> 1;
-    const int Hp = p.Hp, nch = Hp >> 4, nch_half = nch >> 1, nwg = nch;
+    const int Hp = p.Hp, nch = Hp >> 4, nwg = nch;
+    const int nch_half = NCHH > 0 ? NCHH : (nch >> 1);
     const int row0 = wg * 16;
     const int uj = lane & 15, kq = lane >> 4;
     const int kh = wave >> 1, ng = wave & 1;
-    const int Bp = p.Bp;
     const int sync_mode = p.sync_mode;
     float4* Wl = lds4;                      // [nch][64] fragment-ordered weight slab
     float4* red = lds4 + (size_t)nch * 64;  // [2 ng][NTW][64] partial sums of the upper K half
@@ -134,20 +155,29 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
     float* out = p.out[g];
     const int64_t ld = p.ld;
     const float hi = p.max_act > 0.f ? p.max_act : INFINITY;
-    unsigned* ctr = p.counters + g;
+    unsigned* flags = p.counters + 4 + g * 128;  // [2][128] step flags
     unsigned* err = p.counters + 2;
-    float* xg = p.xbuf + (size_t)g * 2 * nch * Bp * 16;
+    const unsigned chunk_stride = (unsigned)p.n_xrows * 64u;  // bytes per 16-unit chunk
+    float* xg = p.xbuf + (size_t)g * p.n_xrows * Hp;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        xg, 0, (int)((size_t)p.n_xrows * Hp * sizeof(float)), 0x00020000);
 
-    // my utterances (fixed over time) and their lengths
     int ub[NTW], uT[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         ub[i] = (ng + 2 * i) * 16 + uj;
         uT[i] = ub[i] < p.B ? p.T_b[ub[i]] : 0;
     }
+    const int c_beg = kh * nch_half, c_end = c_beg + nch_half;
+
+    const int dbg_sel = (p.debug && g == 0 && tid == 0) ? (wg == 0 ? 0 : (wg == nwg - 1 ? 1 : -1)) : -1;
+    auto stamp = [&](int j, int k) {
+        if (dbg_sel >= 0 && j >= 64 && j < 80)
+            p.debug[(dbg_sel * 16 + (j - 64)) * 8 + k] = (unsigned)clock64();
+    };
 
     for (int j = 0; j < p.Tmax; ++j) {
-        const int nact = p.nact[j];
+        stamp(j, 0);
         // four independent accumulators per tile: the 16x16x4 f32 MFMA has a 40-cycle
         // dependent latency against a 32-cycle issue interval
         f32x4 acc[NTW][4];
@@ -157,11 +187,19 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
             for (int q = 0; q < 4; ++q) acc[i][q] = {0.f, 0.f, 0.f, 0.f};
         bool active[NTW];
         int64_t orow[NTW];
+        unsigned xin[NTW], xout[NTW];  // byte offsets (within a chunk) of the previous / this row
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             active[i] = j < uT[i];
             const int t = desc ? uT[i] - 1 - j : j;
             orow[i] = active[i] ? (int64_t)p.rowbase[t] + ub[i] : 0;
+            // exchange rows are indexed by STEP (not by frame): all rows of one 256-byte-aligned
+            // block are written in the same step in both time orders.  Finished / empty slots
+            // read exchange row 0 (valid memory, result discarded).
+            const unsigned xrow = active[i] ? (unsigned)p.xbase[j] + (unsigned)ub[i] : 0u;
+            const unsigned prow = (active[i] && j > 0) ? (unsigned)p.xbase[j - 1] + (unsigned)ub[i] : 0u;
+            xin[i] = prow * 64u + (unsigned)kq * 16u;
+            xout[i] = xrow * 64u + (unsigned)kq * 16u;
         }
         // prefetch the per-frame additive term (independent of the recurrence)
         float4 pre4[NTW], act4[NTW];
@@ -178,47 +216,59 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
         }
 
         if (j > 0) {
-            grid_wait(ctr, (unsigned)j * nwg, err, sync_mode);
-            const float* xr = xg + (size_t)((j - 1) & 1) * nch * Bp * 16;
-            const int c_beg = kh * nch_half, c_end = c_beg + nch_half;
-            // every tile (ng + 2i) with a live utterance at step j
-            bool tile_on[NTW];
+            wait_all(flags, nwg, (unsigned)j, err);
+            stamp(j, 1);
+            // All x loads of a batch are issued, unconditionally, before its first MFMA
+            // (up to 64 float4 = 256 VGPRs per lane): one latency + streaming per step.
+            if constexpr (NCHH > 0) {
+                constexpr int XB = NCHH < 64 / NTW ? NCHH : 64 / NTW;
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) tile_on[i] = (ng + 2 * i) * 16 < nact;
-            // All x loads of the step are issued before the first MFMA (up to 64 float4 =
-            // 256 VGPRs per lane; one wave per SIMD owns the whole register file): the
-            // exchange buffer comes from a remote L2 / the Infinity Cache with microsecond
-            // latency, so the step time is latency + streaming, not latency per batch.
-            constexpr int XB = 64 / NTW;
-            for (int cb = c_beg; cb < c_end; cb += XB) {
-                float4 x[XB][NTW];
+                for (int cb = 0; cb < NCHH; cb += XB) {
+                    float4 x[XB][NTW];
 #pragma unroll
-                for (int u = 0; u < XB; ++u) {
-                    const int c = cb + u;
+                    for (int u = 0; u < XB; ++u)
+                        if (cb + u < NCHH) {
 #pragma unroll
-                    for (int i = 0; i < NTW; ++i) {
-                        if (c < c_end && tile_on[i])
-                            x[u][i] = ld_x(xr + ((size_t)c * Bp + ub[i]) * 16 + 4 * kq, sync_mode);
-                        else
-                            x[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+                            for (int i = 0; i < NTW; ++i)
+                                x[u][i] = ld_x(xrsrc, xin[i], (unsigned)(c_beg + cb + u) * chunk_stride);
+                        }
+                    // keep every load ahead of the first MFMA (the scheduler would otherwise sink
+                    // them next to their uses to save registers and re-expose the latency)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < XB; ++u)
+                        if (cb + u < NCHH) {
+                            const float4 a = Wl[(c_beg + cb + u) * 64 + lane];
+#pragma unroll
+                            for (int i = 0; i < NTW; ++i) { SCTC_MFMA4(acc[i], a, x[u][i]) }
+                        }
                 }
+            } else {
+                constexpr int XB = 64 / NTW;
+                for (int cb = c_beg; cb < c_end; cb += XB) {
+                    float4 x[XB][NTW];
 #pragma unroll
-                for (int u = 0; u < XB; ++u) {
-                    const int c = cb + u;
-                    if (c < c_end) {
-                        const float4 a = Wl[c * 64 + lane];
+                    for (int u = 0; u < XB; ++u) {
+                        const int c = min(cb + u, c_end - 1);
 #pragma unroll
-                        for (int i = 0; i < NTW; ++i) {
-                            if (tile_on[i]) {
-                                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[u][i].x, acc[i][0], 0, 0, 0);
-                                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[u][i].y, acc[i][1], 0, 0, 0);
-                                acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[u][i].z, acc[i][2], 0, 0, 0);
-                                acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[u][i].w, acc[i][3], 0, 0, 0);
-                            }
+                        for (int i = 0; i < NTW; ++i)
+                            x[u][i] = ld_x(xrsrc, xin[i], (unsigned)c * chunk_stride);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < XB; ++u) {
+                        const int c = cb + u;
+                        if (c < c_end) {
+                            const float4 a = Wl[c * 64 + lane];
+#pragma unroll
+                            for (int i = 0; i < NTW; ++i) { SCTC_MFMA4(acc[i], a, x[u][i]) }
                         }
                     }
                 }
+            }
+            if (p.debug) {
+                asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));
+                stamp(j, 2);
             }
             // fold the two K halves: upper half parks its partials in LDS
             if (kh == 1) {
@@ -229,10 +279,10 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
                 }
             }
             __syncthreads();
+            stamp(j, 3);
         }
 
         if (kh == 0) {
-            float* xw = xg + (size_t)(j & 1) * nch * Bp * 16;
 #pragma unroll
             for (int i = 0; i < NTW; ++i) {
                 if (!active[i]) continue;
@@ -257,17 +307,18 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
                     o.w = (act4[i].w > 0.f && act4[i].w < hi) ? pre4[i].w + s.w : 0.f;
                 }
                 *reinterpret_cast<float4*>(out + orow[i] * ld + row0 + 4 * kq) = o;
-                st_x(xw + ((size_t)wg * Bp + ub[i]) * 16 + 4 * kq, o, sync_mode);
+                st_x(xrsrc, xout[i], (unsigned)wg * chunk_stride, o, sync_mode);
             }
         }
-        if (j + 1 < p.Tmax) grid_arrive(ctr, sync_mode);
+        stamp(j, 4);
+        if (j + 1 < p.Tmax) publish_step(flags + wg, (unsigned)(j + 1), sync_mode);
+        stamp(j, 5);
     }
 }
 
-size_t recurrent_xbuf_floats(int Hp, int B)
+size_t recurrent_xbuf_floats(int Hp, int64_t max_xrows)
 {
-    const int Bp = (int)round_up(B, 16);
-    return (size_t)2 * 2 * (Hp / 16) * Bp * 16;
+    return (size_t)2 * (size_t)max_xrows * Hp;  // one chunk-major state copy per direction
 }
 
 int recurrent_supported(int Hp, int B, char* why, int why_len)
@@ -282,12 +333,29 @@ int recurrent_supported(int Hp, int B, char* why, int why_len)
     return 1;
 }
 
+typedef void (*RecKernel)(RecArgs);
+
+template <int NTW>
+static RecKernel pick_kernel(int nch_half)
+{
+    switch (nch_half) {
+        case 16: return brnn_recurrent_kernel<NTW, 16>;   // H = 512
+        case 32: return brnn_recurrent_kernel<NTW, 32>;   // H = 1024
+        case 57: return brnn_recurrent_kernel<NTW, 57>;   // H = 1824
+        case 64: return brnn_recurrent_kernel<NTW, 64>;   // H = 2048
+        default: return brnn_recurrent_kernel<NTW, 0>;
+    }
+}
+
 int launch_recurrent(const RecArgs& a, hipStream_t stream)
 {
     char why[128];
     if (!recurrent_supported(a.Hp, a.B, why, sizeof(why)))
         return set_error(SCTC_ERR_ARG, "recurrent kernel: %s", why);
     if (a.Tmax <= 0 || a.B <= 0) return SCTC_OK;
+    if ((size_t)a.n_xrows * a.Hp * sizeof(float) >= ((size_t)1 << 31))
+        return set_error(SCTC_ERR_ARG, "recurrent kernel: %d exchange rows x %d units exceed the "
+                         "2 GiB buffer addressing", a.n_xrows, a.Hp);
     int dev = 0, cus = 0;
     SCTC_HIP_TRY(hipGetDevice(&dev));
     SCTC_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -298,9 +366,9 @@ int launch_recurrent(const RecArgs& a, hipStream_t stream)
     const int ntiles = (a.B + 15) / 16;
     const int ntw = ntiles <= 2 ? 1 : (ntiles <= 4 ? 2 : 4);
     const size_t smem = sizeof(float4) * ((size_t)nwg * 64 + 2 * ntw * 64);
-    SCTC_HIP_TRY(hipMemsetAsync(a.counters, 0, 4 * sizeof(unsigned), stream));
-    void (*kern)(RecArgs) = ntw == 1 ? brnn_recurrent_kernel<1>
-                            : (ntw == 2 ? brnn_recurrent_kernel<2> : brnn_recurrent_kernel<4>);
+    SCTC_HIP_TRY(hipMemsetAsync(a.counters, 0, REC_COUNTER_WORDS * sizeof(unsigned), stream));
+    RecKernel kern = ntw == 1 ? pick_kernel<1>(nwg / 2)
+                     : (ntw == 2 ? pick_kernel<2>(nwg / 2) : pick_kernel<4>(nwg / 2));
     SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3(2 * nwg), dim3(256), smem, stream, a);

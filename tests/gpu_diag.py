@@ -125,11 +125,40 @@ def sec_brnn(cfgname="cfg3", B=32, sync=None):
     del net
 
 
+def sec_recdbg(sync=0):
+    """per-step timeline of the recurrent kernel (workgroups 0 and last of direction 0)"""
+    from nnets import brnnet
+    os.environ["SCTC_REC_DEBUG"] = "1"
+    os.environ["SCTC_REC_SYNC"] = str(sync)
+    D, A, H, NL, TL, T, U, B = 483, 33, 1824, 5, 3, 200, 20, 32
+    np.random.seed(0)
+    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B)
+    net.initParams()
+    rs = np.random.RandomState(1)
+    feats = torch.randn(B * T, D, device="cuda")
+    labels = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
+    for _ in range(2):
+        net.costAndGradBatch(None, labels, feats_dev=feats, T_b=[T] * B)
+    buf = np.zeros(2 * 2 * 16 * 8, dtype=np.uint32)
+    _sctc.lib().sctc_brnn_debug_read(net._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size)
+    st = buf.reshape(2, 2, 16, 8).astype(np.int64)
+    names = ["wait", "load+mfma", "lds-reduce", "epilogue", "publish"]
+    for ps, pname in enumerate(("forward", "bptt")):
+        for w in range(2):
+            d = np.diff(st[ps, w, :, :6], axis=1) & 0xffffffff
+            step = (np.diff(st[ps, w, :, 0]) & 0xffffffff)
+            print("sync=%d %s wg%s: ticks/step median %d; phases median:" % (sync, pname, "0" if w == 0 else "last", np.median(step)),
+                  ", ".join("%s %d" % (n, v) for n, v in zip(names, np.median(d[1:], axis=0))))
+    del net
+    os.environ["SCTC_REC_DEBUG"] = "0"
+
+
 def main():
     want = sys.argv[1:] or ["info", "gemm", "ctc", "brnn"]
     table = {"info": sec_info, "gemm": sec_gemm, "ctc": sec_ctc,
              "brnn": lambda: sec_brnn("cfg3", 32, 0),
              "brnn1": lambda: sec_brnn("cfg3", 32, 1),
+             "recdbg": lambda: sec_recdbg(0), "recdbg1": lambda: sec_recdbg(1),
              "brnn_small": lambda: sec_brnn("cfg2", 1, 0),
              "brnn4": lambda: sec_brnn("cfg4", 32, 0)}
     for name in want:
