@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsctc_hip.so")
+LIB_PATH = os.environ.get("SCTC_LIB_PATH") or os.path.join(_HERE, "libsctc_hip.so")   # override: kernel-variant experiments
 
 F32, F64 = 0, 1
 

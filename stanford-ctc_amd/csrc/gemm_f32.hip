@@ -2,7 +2,7 @@
 // chain, 157 TFLOP/s dense peak -- MI355X has no TF32/xf32 path, so this IS the
 // matrix-core instruction for the reference's fp32 cm.dot calls).
 //
-// Tiling: 128x128 block tile, BK = 32, 256 threads = 4 waves in a 2x2 grid, each
+// Tiling: 128x128 block tile, BK = 16, 256 threads = 4 waves in a 2x2 grid, each
 // wave owning a 64x64 sub-tile = 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs).
 // Operands are staged through LDS in [k][m] / [k][n] order so that an MFMA
 // fragment read (lane l -> element (k = l>>5, m = l&31)) is a conflict-free
@@ -10,8 +10,10 @@
 // the way into LDS (row stride 129: conflict-free scalar writes), row-contiguous
 // operands are written with ds_write_b128 (row stride 132).  Global loads of tile
 // t+1 are issued before the MFMAs of tile t and written to the other LDS buffer
-// afterwards: one workgroup barrier per K tile.  Two blocks per CU (2 waves/SIMD)
-// overlap one block's barrier/epilogue with the other's MFMAs.
+// afterwards: one workgroup barrier per K tile; the LDS fragments of MFMA step kk+2
+// are requested before the MFMAs of step kk issue.  Three blocks per CU (3 waves per
+// SIMD, 34 KiB LDS each) overlap one block's barrier/epilogue with the others' MFMAs:
+// measured 100-105 TFLOP/s on the cfg-3 shapes vs 88-100 with BK = 32 / 2 blocks.
 // Workgroup ids are remapped so that the blocks of one XCD walk the N tiles of one
 // A row-panel consecutively (panel stays in that XCD's 4 MiB L2).
 #include "common.h"
@@ -21,7 +23,15 @@ namespace sctc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static constexpr int BM = 128, BN = 128, BK = 32, NTHREADS = 256;
+#ifndef SCTC_GEMM_BK
+#define SCTC_GEMM_BK 16
+#endif
+#ifndef SCTC_GEMM_OCC
+#define SCTC_GEMM_OCC 3
+#endif
+static constexpr int BM = 128, BN = 128, BK = SCTC_GEMM_BK, NTHREADS = 256;
+static constexpr int KQ = BK / 4;                    // float4 per row of a K-contiguous operand tile
+static constexpr int NLD = BM * BK / 4 / NTHREADS;   // float4 loads per thread per operand per K tile
 static constexpr int LD_K = 129;  // LDS row stride for transposed (K-contiguous) operands
 static constexpr int LD_R = 132;  // LDS row stride for row-contiguous operands
 static constexpr int LDS_OPERAND = BK * LD_R;  // floats per operand per buffer (max of the two)
@@ -37,7 +47,7 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& p, float v, int r
 }
 
 template <bool AK, bool BKC>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmArgs p)
+__global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDA = AK ? LD_K : LD_R;
@@ -65,14 +75,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmArgs p)
     const int kt_beg = blockIdx.y * per;
     const int kt_end = min(ktiles, kt_beg + per);
 
-    float4 ra[4], rb[4];
+    float4 ra[NLD], rb[NLD];
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NLD; ++q) {
             const int f = tid + NTHREADS * q;
             if constexpr (AK) {
-                const int r = f >> 3, k = k0 + 4 * (f & 7), row = m0 + r;
+                const int r = f / KQ, k = k0 + 4 * (f % KQ), row = m0 + r;
                 ra[q] = (row < M && k < K)
                             ? *reinterpret_cast<const float4*>(p.A + (int64_t)row * p.lda + k)
                             : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -86,7 +96,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmArgs p)
                 ra[q] = v;
             }
             if constexpr (BKC) {
-                const int r = f >> 3, k = k0 + 4 * (f & 7), row = n0 + r;
+                const int r = f / KQ, k = k0 + 4 * (f % KQ), row = n0 + r;
                 rb[q] = (row < N && k < K)
                             ? *reinterpret_cast<const float4*>(p.B + (int64_t)row * p.ldb + k)
                             : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -105,10 +115,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmArgs p)
         float* a = As + buf * LDS_OPERAND;
         float* b = Bs + buf * LDS_OPERAND;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NLD; ++q) {
             const int f = tid + NTHREADS * q;
             if constexpr (AK) {
-                const int r = f >> 3, kq = 4 * (f & 7);
+                const int r = f / KQ, kq = 4 * (f % KQ);
                 a[(kq + 0) * LDA + r] = ra[q].x;
                 a[(kq + 1) * LDA + r] = ra[q].y;
                 a[(kq + 2) * LDA + r] = ra[q].z;
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmArgs p)
                 *reinterpret_cast<float4*>(a + kr * LDA + m) = ra[q];
             }
             if constexpr (BKC) {
-                const int r = f >> 3, kq = 4 * (f & 7);
+                const int r = f / KQ, kq = 4 * (f % KQ);
                 b[(kq + 0) * LDB + r] = rb[q].x;
                 b[(kq + 1) * LDB + r] = rb[q].y;
                 b[(kq + 2) * LDB + r] = rb[q].z;
@@ -149,14 +159,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmArgs p)
             if (more) gload(kt + 1);
             const float* a = As + buf * LDS_OPERAND + kh * LDA + wm * 64 + li;
             const float* b = Bs + buf * LDS_OPERAND + kh * LDB + wn * 64 + li;
+            // fragments of step kk+2 are requested from LDS before the MFMAs of step kk issue,
+            // so the ~100-cycle ds_read latency hides under 4 x 64 cycles of matrix work
+            float a0 = a[0], a1 = a[32], b0 = b[0], b1 = b[32];
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
-                const float a0 = a[kk * LDA], a1 = a[kk * LDA + 32];
-                const float b0 = b[kk * LDB], b1 = b[kk * LDB + 32];
+                float a0n = 0.f, a1n = 0.f, b0n = 0.f, b1n = 0.f;
+                if (kk + 2 < BK) {
+                    a0n = a[(kk + 2) * LDA];
+                    a1n = a[(kk + 2) * LDA + 32];
+                    b0n = b[(kk + 2) * LDB];
+                    b1n = b[(kk + 2) * LDB + 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
             }
             if (more) lstore(buf ^ 1);
             __syncthreads();
@@ -168,17 +188,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmArgs p)
     const bool partial = p.splits > 1;
     float* out = partial ? p.splitk_ws + (int64_t)blockIdx.y * M * N : p.C;
     const int64_t ldo = partial ? N : p.ldc;
+    // The auxiliary operands (bias / mask / addend / old C) of a 32x32 tile are fetched as one
+    // batch of independent loads before any of them is used: a load-use pair per element would
+    // serialise 64 L2 round trips per thread.
+    const bool has_mask = !partial && p.mask, has_add = !partial && p.addend;
+    const bool has_acc = !partial && p.accumulate;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            const int rbase = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+            const bool col_ok = col < N;
+            const float bias = (!partial && p.bias && col_ok) ? p.bias[col] : 0.f;
+            float mk[16], ad[16], cc[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < M && col < N) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                const bool ok = col_ok && row < M;
+                mk[r] = (has_mask && ok) ? p.mask[(int64_t)row * p.ldmask + col] : 1.f;
+                ad[r] = (has_add && ok) ? p.addend[(int64_t)row * p.ldadd + col] : 0.f;
+                cc[r] = (has_acc && ok) ? p.C[(int64_t)row * p.ldc + col] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (col_ok && row < M) {
                     float v = acc[i][j][r];
-                    if (!partial) v = gemm_epilogue(p, v, row, col);
+                    if (!partial) {
+                        v += bias;
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        if (has_mask) v = mk[r] > 0.f ? v : 0.f;
+                        if (has_add) v += p.add_scale * ad[r];
+                        if (has_acc) v += cc[r];
+                    }
                     out[(int64_t)row * ldo + col] = v;
                 }
             }
@@ -205,7 +248,7 @@ int64_t gemm_plan_splits(int M, int N, int K, int* splits)
     // 256 CUs x 2 resident blocks = 512 slots.  A grid that is not a multiple of that leaves a
     // partial last round (225 tiles x 3 splits = 675 blocks ran at 66 %); pick the split that
     // fills whole rounds best, keeping >= 8 K tiles per split.
-    const int tiles = mt * nt, slots = 512;
+    const int tiles = mt * nt, slots = 256 * SCTC_GEMM_OCC;
     if (tiles < 2 * slots) {
         double best = 0.0;
         const int smax = std::min(64, std::max(1, ktiles / 8));
