@@ -76,10 +76,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local)
+    # SCTC_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing test of the N>1 path
+    # on a 1-GPU box); the real run uses nccl (= RCCL over xGMI), one rank per GPU
+    backend = os.environ.get("SCTC_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     import _sctc

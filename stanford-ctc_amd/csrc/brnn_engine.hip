@@ -29,6 +29,10 @@ void ctc_free_stage(void* p);
 using namespace sctc;
 
 static constexpr int PAD = 32;
+// Row strides are multiples of 64 floats (256 B): with the natural stride of H = 1824
+// (7296 B = 57 x 128 B) a GEMM whose A and C matrices share that stride ran 13 % slower
+// (measured: 102 vs 115 TFLOP/s), any multiple of 256 B is fine.
+static inline int LD(int padded_dim) { return (int)((padded_dim + 63) / 64 * 64); }
 static constexpr int CTC_LP_MAX = 2048;  // worst-case lattice row (2U+1 <= 2048)
 
 struct sctc_brnn {
@@ -127,9 +131,9 @@ static void build_tensor_table(const Dims& d, std::vector<sctc_tensor_info>* t, 
     for (int l = 0; l <= d.NL; ++l) {
         const int in = l == 0 ? d.D : d.H, inp = l == 0 ? d.Dp : d.Hp;
         const int out = l == d.NL ? d.A : d.H, outp = l == d.NL ? d.Ap : d.Hp;
-        sctc_tensor_info w = {off, out, in, inp, 0};
+        sctc_tensor_info w = {off, out, in, LD(inp), 0};
         t->push_back(w);
-        off += (int64_t)outp * inp;
+        off += (int64_t)outp * LD(inp);
         sctc_tensor_info b = {off, out, 1, 1, 1};
         t->push_back(b);
         off += outp;
@@ -137,9 +141,9 @@ static void build_tensor_table(const Dims& d, std::vector<sctc_tensor_info>* t, 
     }
     if (d.TL > 0) {
         for (int k = 0; k < 2; ++k) {
-            sctc_tensor_info w = {off, d.H, d.H, d.Hp, 2};
+            sctc_tensor_info w = {off, d.H, d.H, LD(d.Hp), 2};
             t->push_back(w);
-            off += (int64_t)d.Hp * d.Hp;
+            off += (int64_t)d.Hp * LD(d.Hp);
             cnt += (int64_t)d.H * d.H;
         }
     }
@@ -155,20 +159,20 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
     const int64_t F = c->max_frames;
     const int Bm = c->max_utts;
     auto f = [&](int64_t n) { return ar.take<float>((size_t)n); };
-    float* X0 = f(F * d.Dp);
+    float* X0 = f(F * LD(d.Dp));
     std::vector<float*> act(d.NL + 1);
     act[0] = X0;
-    for (int i = 1; i <= d.NL; ++i) act[i] = f(F * d.Hp);
+    for (int i = 1; i <= d.NL; ++i) act[i] = f(F * LD(d.Hp));
     float *Z = nullptr, *hF = nullptr, *hB = nullptr;
-    if (d.TL > 0) { Z = f(F * d.Hp); hF = f(F * d.Hp); hB = f(F * d.Hp); }
-    float* logits = f(F * d.Ap);
-    float* probs = f(F * d.Ap);
+    if (d.TL > 0) { Z = f(F * LD(d.Hp)); hF = f(F * LD(d.Hp)); hB = f(F * LD(d.Hp)); }
+    float* logits = f(F * LD(d.Ap));
+    float* probs = f(F * LD(d.Ap));
     float *dlogits = nullptr, *dA = nullptr, *dBuf = nullptr, *dF = nullptr, *dBk = nullptr;
     if (c->train) {
-        dlogits = f(F * d.Ap);
-        dA = f(F * d.Hp);
-        dBuf = f(F * d.Hp);
-        if (d.TL > 0) { dF = f(F * d.Hp); dBk = f(F * d.Hp); }
+        dlogits = f(F * LD(d.Ap));
+        dA = f(F * LD(d.Hp));
+        dBuf = f(F * LD(d.Hp));
+        if (d.TL > 0) { dF = f(F * LD(d.Hp)); dBk = f(F * LD(d.Hp)); }
     }
     int32_t* d_rowbase = ar.take<int32_t>(F);
     int32_t* d_nact = ar.take<int32_t>(F);
@@ -354,7 +358,7 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
     const int64_t N = h->N;
     pt.begin(SCTC_PHASE_OTHER);
     // brnnet.py:136 hActs[0] <- data, here also the re-ordering into the packed layout
-    SCTC_TRY(launch_gather_rows(h->X0, h->Dp, mb->feats_dev, h->D, h->d_src_row, N, h->D, s));
+    SCTC_TRY(launch_gather_rows(h->X0, LD(h->Dp), mb->feats_dev, h->D, h->d_src_row, N, h->D, s));
     for (int i = 1; i <= h->NL + 1; ++i) {
         pt.begin(SCTC_PHASE_FWD_GEMM);
         const int l = i - 1;
@@ -363,10 +367,10 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
         const int outp = i == h->NL + 1 ? h->Ap : h->Hp;
         GemmArgs g = gemm_defaults();
         g.A = h->act[i - 1];           // [N][inp]
-        g.lda = inp;
+        g.lda = LD(inp);
         g.a_kcontig = 1;
         g.B = h->params + wi.offset;   // W [outp][inp]: B(k,n) = W[n][k]
-        g.ldb = inp;
+        g.ldb = LD(inp);
         g.b_kcontig = 1;
         g.M = (int)N;
         g.N = outp;
@@ -374,7 +378,7 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
         g.bias = tensor_ptr(h, h->params, bias_index(h, l));   // add_col_vec, brnnet.py:141
         float* dst = i == h->NL + 1 ? h->logits : (i == h->TL ? h->Z : h->act[i]);
         g.C = dst;
-        g.ldc = outp;
+        g.ldc = LD(outp);
         g.relu = (i <= h->NL && i != h->TL) ? 1 : 0;             // brnnet.py:155-157
         SCTC_TRY(launch_gemm_f32(g, s));
         if (i == h->TL) {
@@ -383,7 +387,7 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
             memset(&r, 0, sizeof(r));
             r.W[0] = tensor_ptr(h, h->params, wf_index(h));
             r.W[1] = tensor_ptr(h, h->params, wb_index(h));
-            r.ldw = h->Hp;
+            r.ldw = LD(h->Hp);
             r.transpose = 0;
             r.descending[0] = 0;
             r.descending[1] = 1;
@@ -391,7 +395,7 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
             r.act[0] = r.act[1] = nullptr;
             r.out[0] = h->hF;
             r.out[1] = h->hB;
-            r.ld = h->Hp;
+            r.ld = LD(h->Hp);
             r.Hp = h->Hp;
             r.B = h->B;
             r.Tmax = h->Tmax;
@@ -407,11 +411,11 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
             SCTC_TRY(launch_recurrent(r, s));
             pt.begin(SCTC_PHASE_OTHER);
             // hActs[i] = hActsFor + hActsBack, brnnet.py:153
-            SCTC_TRY(launch_add(h->act[i], h->hF, h->hB, N * h->Hp, s));
+            SCTC_TRY(launch_add(h->act[i], h->hF, h->hB, N * LD(h->Hp), s));
         }
     }
     pt.begin(SCTC_PHASE_CTC);
-    SCTC_TRY(launch_softmax_rows(h->logits, h->probs, N, h->A, h->Ap, s));  // brnnet.py:161-168
+    SCTC_TRY(launch_softmax_rows(h->logits, h->probs, N, h->A, LD(h->Ap), s));  // brnnet.py:161-168
     return SCTC_OK;
 }
 
@@ -457,7 +461,7 @@ static int run_ctc(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s)
     bt.A = h->A;
     bt.blank = 0;  // brnnet.py:175-176 blank=0
     bt.dtype = SCTC_F32;
-    bt.ld = h->Ap;
+    bt.ld = LD(h->Ap);
     bt.T_b = h->Ts.data();
     bt.U_b = U.data();
     bt.frame_off = frame_off.data();
@@ -486,7 +490,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
     const int acc = (flags & SCTC_FLAG_ACCUMULATE) ? 1 : 0;
     const float reg = h->cfg.reg;
     const float* d_in = h->dlogits;
-    int d_in_ld = h->Ap;
+    int d_in_ld = LD(h->Ap);
     float* bufs[2] = {h->dA, h->dBuf};
     int which = 0;
     for (int i = h->NL; i >= 0; --i) {          // brnnet.py:191-243
@@ -502,15 +506,15 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             g.lda = d_in_ld;
             g.a_kcontig = 0;
             g.B = h->act[i];        // B(k=frame, n=in) = act[frame][in]
-            g.ldb = inp;
+            g.ldb = LD(inp);
             g.b_kcontig = 0;
             g.M = outp;
             g.N = inp;
             g.K = (int)N;
             g.C = h->grads + wi.offset;
-            g.ldc = inp;
+            g.ldc = LD(inp);
             g.accumulate = acc;
-            if (reg > 0.f) { g.addend = W; g.ldadd = inp; g.add_scale = reg; }
+            if (reg > 0.f) { g.addend = W; g.ldadd = LD(inp); g.add_scale = reg; }
             g.splitk_ws = h->splitk_ws;
             int splits = 1;
             gemm_plan_splits(g.M, g.N, g.K, &splits);
@@ -531,14 +535,14 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             g.lda = d_in_ld;
             g.a_kcontig = 1;
             g.B = W;                // B(k=out, n=in) = W[out][in]
-            g.ldb = inp;
+            g.ldb = LD(inp);
             g.b_kcontig = 0;
             g.M = (int)N;
             g.N = inp;
             g.K = outp;
             g.C = d_out;
-            g.ldc = inp;
-            if (i != h->TL) { g.mask = h->act[i]; g.ldmask = h->Hp; }
+            g.ldc = LD(inp);
+            if (i != h->TL) { g.mask = h->act[i]; g.ldmask = LD(h->Hp); }
             SCTC_TRY(launch_gemm_f32(g, s));
         }
         if (i == h->TL) {
@@ -547,7 +551,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             memset(&r, 0, sizeof(r));
             r.W[0] = tensor_ptr(h, h->params, wf_index(h));
             r.W[1] = tensor_ptr(h, h->params, wb_index(h));
-            r.ldw = h->Hp;
+            r.ldw = LD(h->Hp);
             r.transpose = 1;
             r.descending[0] = 1;   // deltasFor runs from T-1 down, brnnet.py:217-218
             r.descending[1] = 0;   // deltasBack runs from 0 up,    brnnet.py:219-220
@@ -556,7 +560,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             r.act[1] = h->hB;
             r.out[0] = h->dF;
             r.out[1] = h->dBk;
-            r.ld = h->Hp;
+            r.ld = LD(h->Hp);
             r.Hp = h->Hp;
             r.B = h->B;
             r.Tmax = h->Tmax;
@@ -577,22 +581,22 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
                 const sctc_tensor_info& ri = h->tinfo[k == 0 ? wf_index(h) : wb_index(h)];
                 GemmArgs g = gemm_defaults();
                 g.A = k == 0 ? h->dF : h->dBk;
-                g.lda = h->Hp;
+                g.lda = LD(h->Hp);
                 g.a_kcontig = 0;
                 g.idx_a = k == 0 ? h->d_idx_hi : h->d_idx_lo;
                 g.B = k == 0 ? h->hF : h->hB;
-                g.ldb = h->Hp;
+                g.ldb = LD(h->Hp);
                 g.b_kcontig = 0;
                 g.idx_b = k == 0 ? h->d_idx_lo : h->d_idx_hi;
                 g.M = h->Hp;
                 g.N = h->Hp;
                 g.K = (int)h->npairs;
                 g.C = h->grads + ri.offset;
-                g.ldc = h->Hp;
+                g.ldc = LD(h->Hp);
                 g.accumulate = acc;
                 if (reg > 0.f) {           // brnnet.py:244-247
                     g.addend = h->params + ri.offset;
-                    g.ldadd = h->Hp;
+                    g.ldadd = LD(h->Hp);
                     g.add_scale = reg;
                 }
                 g.splitk_ws = h->splitk_ws;
@@ -603,10 +607,10 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             }
             // deltasOut = deltasFor + deltasBack, brnnet.py:233
             pt.begin(SCTC_PHASE_OTHER);
-            SCTC_TRY(launch_add(d_out, h->dF, h->dBk, N * h->Hp, s));
+            SCTC_TRY(launch_add(d_out, h->dF, h->dBk, N * LD(h->Hp), s));
         }
         d_in = d_out;
-        d_in_ld = h->Hp;
+        d_in_ld = LD(h->Hp);
         which ^= 1;
     }
     return SCTC_OK;
@@ -680,7 +684,7 @@ int sctc_brnn_create(const sctc_brnn_config* cfg, float* params_dev, float* grad
     carve(cfg, d, h, workspace_dev, workspace_bytes);
     // padding columns of the CTC gradient are never written by the kernels: zero once
     hipError_t e = hipSuccess;
-    if (cfg->train) e = hipMemset(h->dlogits, 0, sizeof(float) * h->maxF * h->Ap);
+    if (cfg->train) e = hipMemset(h->dlogits, 0, sizeof(float) * h->maxF * LD(h->Ap));
     if (e != hipSuccess) {
         delete h;
         return set_error(SCTC_ERR_HIP, "brnn_create: %s", hipGetErrorString(e));
@@ -776,7 +780,7 @@ int sctc_brnn_forward(sctc_brnn_t h, const sctc_minibatch* mb, float* probs_dev,
     SCTC_TRY(make_plan(h, mb, false, s));
     SCTC_TRY(run_forward(h, mb, s, pt));
     // probs back in the caller's per-utterance order, brnnet.py:170-173
-    SCTC_TRY(launch_scatter_rows(probs_dev, h->A, h->probs, h->Ap, h->d_src_row, h->N, h->A, s));
+    SCTC_TRY(launch_scatter_rows(probs_dev, h->A, h->probs, LD(h->Ap), h->d_src_row, h->N, h->A, s));
     pt.end();
     return check_recurrent_error(h, s);
 }

@@ -162,6 +162,9 @@ __global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmA
             // fragments of step kk+2 are requested from LDS before the MFMAs of step kk issue,
             // so the ~100-cycle ds_read latency hides under 4 x 64 cycles of matrix work
             float a0 = a[0], a1 = a[32], b0 = b[0], b1 = b[32];
+#ifdef SCTC_GEMM_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
                 float a0n = 0.f, a1n = 0.f, b0n = 0.f, b1n = 0.f;
@@ -178,6 +181,9 @@ __global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmA
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
                 a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
             }
+#ifdef SCTC_GEMM_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if (more) lstore(buf ^ 1);
             __syncthreads();
             buf ^= 1;

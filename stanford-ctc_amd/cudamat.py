@@ -4,7 +4,7 @@ runNNet.py:117-120; brnnet.py:13,255-256,264-276) -- an API facade (names only) 
 HIP buffers and libsctc_hip.so.  No cudamat / CUDA code is involved.
 
 A CUDAMatrix is a device matrix of logical shape (rows, cols) stored row-major and
-zero-padded to [ceil32(rows)][ceil32(cols)] (a (rows,1) vector: [ceil32(rows)]), the
+zero-padded to [ceil32(rows)][ceil64(cols)] (a (rows,1) vector: [ceil32(rows)]), the
 layout of the BRNN engine's flat parameter buffer, so same-shape matrices can be
 combined with one contiguous kernel.  PyTorch only provides the allocation.
 """
@@ -20,10 +20,11 @@ def _pad32(n):
 
 
 def padded_layout(rows, cols):
-    """-> (rows_p, ld) of a logical (rows, cols) matrix"""
+    """-> (rows_p, ld) of a logical (rows, cols) matrix: rows padded to 32, the row stride to
+    64 floats (256 B, see LD() in csrc/brnn_engine.hip)"""
     if cols == 1:
         return _pad32(rows), 1
-    return _pad32(rows), _pad32(cols)
+    return _pad32(rows), (int(cols) + 63) // 64 * 64
 
 
 def cuda_set_device(n):

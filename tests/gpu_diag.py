@@ -68,6 +68,47 @@ def sec_gemm():
         del a, b, c
 
 
+def sec_gemm2():
+    """shape sweep around the cfg-3 forward GEMM"""
+    L = _sctc.lib()
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    for (M, N, K) in ((32000, 1824, 1824), (32000, 1792, 1824), (32000, 1920, 1824), (32768, 2048, 2048),
+                      (8192, 1824, 1824), (32000, 1824, 8192), (8192, 8192, 1824), (3072, 1824, 1824),
+                      (6144, 1824, 1824), (12288, 1824, 1824)):
+        a = torch.randn((M, K), device="cuda")
+        b = torch.randn((N, K), device="cuda")
+        c = torch.empty((M, N), device="cuda")
+
+        def run():
+            rc = L.sctc_gemm_f32(a.data_ptr(), K, 1, b.data_ptr(), K, 1, c.data_ptr(), N, M, N, K, None, 0,
+                                 ws.data_ptr(), ws.numel(), None)
+            assert rc == 0
+        ms = timed(run)
+        print("gemm NT M=%d N=%d K=%d blocks=%d: %.3f ms  %.1f TFLOP/s" %
+              (M, N, K, ((M + 127) // 128) * ((N + 127) // 128), ms, 2.0 * M * N * K / ms / 1e9))
+        del a, b, c
+
+
+def sec_gemm3():
+    """does the N=1824 slowdown come from the partial tile or from the C row stride?"""
+    L = _sctc.lib()
+    M, K = 32000, 1824
+    for (N, ldc, lda) in ((1824, 1824, 1824), (1824, 1920, 1824), (1920, 1920, 1824), (1824, 2048, 1824),
+                          (1824, 1824, 1856), (1824, 1856, 1856), (1792, 1792, 1824), (1824, 1888, 1824)):
+        a = torch.randn((M, lda), device="cuda")
+        b = torch.randn((N, lda), device="cuda")
+        c = torch.empty((M, ldc), device="cuda")
+
+        def run():
+            rc = L.sctc_gemm_f32(a.data_ptr(), lda, 1, b.data_ptr(), lda, 1, c.data_ptr(), ldc, M, N, K, None, 0,
+                                 None, 0, None)
+            assert rc == 0
+        ms = timed(run)
+        print("gemm NT M=%d N=%d K=%d ldc=%d lda=ldb=%d: %.3f ms  %.1f TFLOP/s" %
+              (M, N, K, ldc, lda, ms, 2.0 * M * N * K / ms / 1e9))
+        del a, b, c
+
+
 def sec_ctc():
     import ctc_fast
     rs = np.random.RandomState(0)
@@ -155,7 +196,7 @@ def sec_recdbg(sync=0):
 
 def main():
     want = sys.argv[1:] or ["info", "gemm", "ctc", "brnn"]
-    table = {"info": sec_info, "gemm": sec_gemm, "ctc": sec_ctc,
+    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "ctc": sec_ctc,
              "brnn": lambda: sec_brnn("cfg3", 32, 0),
              "brnn1": lambda: sec_brnn("cfg3", 32, 1),
              "recdbg": lambda: sec_recdbg(0), "recdbg1": lambda: sec_recdbg(1),

@@ -63,10 +63,10 @@ def test_argument_errors_need_no_gpu(sctc):
     cfg = sctc.BrnnConfig(20, 6, 30, 3, 2, 10, 1, 20.0, 0.0, 1)
     sizes = sctc.BrnnSizes()
     assert L.sctc_brnn_query(ctypes.byref(cfg), ctypes.byref(sizes)) == 0
-    # 20x30 -> [32][32], 30x30 -> [32][32] x2, 30x6 -> [32][32], biases 32 each, Wf, Wb
+    # weights [32 rows][64-float stride], biases 32 each, Wf, Wb
     assert sizes.n_tensors == 2 * 4 + 2
     assert sizes.param_count == 20 * 30 + 30 + 2 * (30 * 30 + 30) + 30 * 6 + 6 + 2 * 30 * 30
-    assert sizes.param_elems == 4 * (32 * 32 + 32) + 2 * 32 * 32
+    assert sizes.param_elems == 4 * (32 * 64 + 32) + 2 * 32 * 64
     assert sizes.workspace_bytes > 0
     bad = sctc.BrnnConfig(20, 6, 4096, 3, 2, 10, 1, 20.0, 0.0, 1)   # needs 512 resident workgroups
     assert L.sctc_brnn_query(ctypes.byref(bad), ctypes.byref(sizes)) == -1
@@ -99,6 +99,7 @@ def test_reference_surface_names(sctc):
         assert callable(getattr(cm.CUDAMatrix, name))
     assert callable(cm.cuda_set_device) and callable(cm.cublas_init)
     assert cm.padded_layout(1824, 483) == (1824, 512) and cm.padded_layout(33, 1) == (64, 1)
+    assert cm.padded_layout(1824, 1824) == (1824, 1856)
     assert ctc_fast.collapse_best_path(np.array([0, 3, 3, 0, 3, 1, 4, 4, 8, 5, 0, 5])) == \
         ([3, 3, 4, 5, 5], [2, 4, 7, 9, 11])
 
