@@ -201,7 +201,9 @@ def main():
              "brnn1": lambda: sec_brnn("cfg3", 32, 1),
              "recdbg": lambda: sec_recdbg(0), "recdbg1": lambda: sec_recdbg(1),
              "brnn_small": lambda: sec_brnn("cfg2", 1, 0),
-             "brnn4": lambda: sec_brnn("cfg4", 32, 0)}
+             "brnn4": lambda: sec_brnn("cfg4", 32, None),
+             "brnn5": lambda: sec_brnn("cfg5", 1, None), "brnn5b": lambda: sec_brnn("cfg5", 8, None),
+             "brnn2": lambda: sec_brnn("cfg2", 1, None), "brnn1u": lambda: sec_brnn("cfg3", 1, None)}
     for name in want:
         print("==== %s" % name, flush=True)
         try:

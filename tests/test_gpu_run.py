@@ -1,0 +1,78 @@
+"""End-to-end driver test on the GPU: runNNet.run (train, checkpoint side files, resume) and
+--test (writeLikelihoods: Kaldi BFM ark + pickle), on tiny synthetic shards in the reference's
+on-disk format.  Checks the run-directory contract of ctc_fast/runNNet.py:143-205 and that the
+cost goes down."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from tests.test_dataloader import write_shard
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_resume_and_export(tmp_path):
+    import torch
+    assert torch.cuda.is_available()
+    import runNNet
+    import writeLikelihoods as wl
+    rs = np.random.RandomState(0)
+    raw = img = 12
+    data = tmp_path / "data"
+    data.mkdir()
+    A = 6
+    for n in (1, 2):
+        utts = [("f%d_u%d" % (n, i), int(rs.randint(12, 30)), list(rs.randint(1, A, size=3)))
+                for i in range(6)]
+        write_shard(data, n, utts, raw, rs)
+    out = tmp_path / "run"
+    common = ["--layerSize", "32", "--numLayers", "3", "--temporalLayer", "2", "--inputDim", str(img),
+              "--rawDim", str(raw), "--outputDim", str(A), "--maxUttLen", "40", "--numFiles", "2",
+              "--dataDir", str(data) + "/", "--step", "1e-3", "--momentum", "0.9", "--save_every", "1"]
+    opt, nn = runNNet.run(common + ["--epochs", "1", "--outputDir", str(out)])
+    assert (out / "epoch").read_text() == "0" and opt.it == 12
+    assert opt.alpha == pytest.approx(1e-3 / 1.3)
+    (out / "sentinel").unlink()
+    # resume for a second epoch: state comes from params.pk, the step from step/anneal**epoch
+    cfg = json.loads((out / "cfg.json").read_text())
+    cfg["epochs"] = 2
+    (out / "cfg.json").write_text(json.dumps(cfg))
+    opt, nn = runNNet.run(["--cfg_file", str(out / "cfg.json")])
+    assert opt.it == 24 and opt.alpha == pytest.approx(1e-3 / 1.3 ** 2)
+    for name in ("cfg.json", "params.pk", "params.pk.epoch00", "params.pk.epoch01", "epoch", "num_files",
+                 "last_cost", "sentinel", "train.log"):
+        assert (out / name).exists(), name
+    assert (out / "epoch").read_text() == "1"
+    cfg = json.loads((out / "cfg.json").read_text())
+    assert cfg["layerSize"] == 32 and cfg["param_count"] == nn._param_count
+    with open(out / "params.pk", "rb") as f:
+        it, costt, expcost, vel = pickle.load(f)
+        stack = pickle.load(f)
+    assert it == 24 and len(costt) == 24 and len(stack) == 3 + 3
+    assert np.mean(costt[-6:]) < np.mean(costt[:6])               # it learns
+    # test mode: log-likelihood export
+    lik = tmp_path / "lik"
+    runNNet.run(["--cfg_file", str(out / "cfg.json"), "--test", "--dataDir", str(data) + "/",
+                 "--numFiles", "2", "--likDir", str(lik)])
+    ark = wl.read_ark(str(lik / "loglikelihoods1.ark"))
+    with open(lik / "loglikelihoods_1.pk", "rb") as f:
+        pk = pickle.load(f)
+    assert sorted(ark) == sorted(pk) and len(ark) == 6
+    for k, m in ark.items():
+        assert m.shape[1] == A and m.dtype == np.float32
+        np.testing.assert_array_equal(m, pk[k].T)
+        np.testing.assert_allclose(np.exp(m.astype(np.float64)).sum(axis=1), 1.0, rtol=1e-4)
+    # the exported probabilities are those of the trained network
+    import dataLoader as dl
+    from nnets import brnnet
+    loader = dl.DataLoader(str(data) + "/", raw, img)
+    dd, _, keys, _ = loader.loadDataFileDict(1)
+    net = brnnet.NNet(img, A, 32, 3, 40, train=False, temporalLayer=2)
+    with open(out / "params.pk", "rb") as f:
+        pickle.load(f)
+        net.fromFile(f)
+    p = net.costAndGrad(dd[keys[0]])
+    np.testing.assert_allclose(np.log(p).T, ark[keys[0]], rtol=1e-5, atol=1e-6)
