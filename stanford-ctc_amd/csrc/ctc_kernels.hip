@@ -21,16 +21,15 @@
 // preserved), and the band [start,end) maps onto itself.  Its lattice is stored in
 // s' order and read back reversed by ctc_grad.
 //
-// Scaling: like the reference every frame is renormalised by c_t = sum over the
-// band (ctc_fast.pyx:70-76).  We multiply by r_t = fl(1/c_t) and account
-// llForward -= log(r_t) in float64, which is exact for whatever r_t was applied.
+// Scaling: the reference renormalises every frame by c_t = sum over the band
+// (ctc_fast.pyx:70-76).  We multiply by r = fl(1/c) at the rescale points (see the lattice
+// kernel) and account llForward -= log(r) in float64, exact for whatever r was applied.
 #include "common.h"
 #include "ctc_kernels.h"
 #include "xlane.h"
 
 namespace sctc {
 
-static constexpr int PF = 8;  // frames of probabilities prefetched ahead of the recursion
 
 template <typename R>
 struct Vec;
@@ -145,12 +144,29 @@ __device__ __forceinline__ int64_t frame_row(const CtcUtt& u, const int32_t* row
 
 // K states per lane (even), NA = ceil(A/64) probability registers per frame.
 // RI: storage type of probs; the recursion itself runs in float64 (see ctc_kernels.h).
+//
+// Rescaling.  The reference divides every frame by its band sum c_t and accumulates
+// llForward = sum_t log c_t (ctc_fast.pyx:70-76); the per-frame scale cancels in the
+// gradient (:138-145).  Here a frame is rescaled only every RS-th step (RS = 4 for float32
+// probabilities, whose smallest value 1e-45 keeps four unscaled float64 steps above 1e-180;
+// RS = 1, the reference's schedule, for float64 probabilities): llForward is the log of the
+// last frame's mass minus the logs of the applied factors, the same number, while the
+// 64-lane reduction + division leave the per-step dependency chain.
 template <typename RI, int K, int NA>
 __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
 {
     using R = double;
     static_assert(K % 2 == 0 && K >= 2, "K must be even");
     constexpr int KH = K / 2;
+#ifdef SCTC_CTC_RS
+    constexpr int RS = SCTC_CTC_RS;
+#else
+    constexpr int RS = sizeof(RI) == 4 ? 4 : 1;
+#endif
+    // Frames of probabilities prefetched per block.  gfx950 counts loads and stores in ONE
+    // in-order counter (vmcnt), so waiting for a block's prefetch also waits for the lattice
+    // rows stored before it: one HBM write latency per block.  Long blocks amortise it.
+    constexpr int PF = K <= 4 ? 32 : (K <= 8 ? 16 : 8);
     const int b = blockIdx.x;
     const int dir = blockIdx.y;  // 0: alpha, 1: beta (== alpha of the reversed problem)
     const int lane = threadIdx.x;
@@ -187,32 +203,47 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
     const int64_t ld = p.ld;
     const int A = p.A;
 
-    auto load_frame = [&](int tau, R (&dst)[NA]) {
+    // a frame's probabilities stay in their storage type until they are gathered
+    auto load_frame = [&](int tau, RI (&dst)[NA]) {
         const int t = dir ? T - 1 - tau : tau;
         const RI* yr = probs + frame_row(u, p.rowbase, t) * ld;
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int k = lane + 64 * q;
-            dst[q] = k < A ? (R)yr[k] : (R)0;   // probs.astype(np.float64), brnnet.py:175
+            dst[q] = k < A ? yr[k] : (RI)0;
         }
     };
-    auto gather = [&](const R (&y)[NA], int k) -> R {
-        R out = lane_gather(y[0], k & 63);
+    auto gather = [&](const RI (&y)[NA], int k) -> R {
+        RI out = lane_gather(y[0], k & 63);
 #pragma unroll
         for (int q = 1; q < NA; ++q) {
-            R o = lane_gather(y[q], k & 63);
+            RI o = lane_gather(y[q], k & 63);
             if ((k >> 6) == q) out = o;
         }
-        return out;
+        return (R)out;   // probs.astype(np.float64), brnnet.py:175
     };
-    auto bcast = [&](const R (&y)[NA], int k) -> R {
-        R out = lane_bcast(y[0], k & 63);
+    auto bcast = [&](const RI (&y)[NA], int k) -> R {
+        RI out = lane_bcast(y[0], k & 63);
 #pragma unroll
         for (int q = 1; q < NA; ++q) {
-            R o = lane_bcast(y[q], k & 63);
+            RI o = lane_bcast(y[q], k & 63);
             if ((k >> 6) == q) out = o;
         }
-        return out;
+        return (R)out;
+    };
+    auto store_row = [&](int tau, const R (&v)[K]) {
+#ifdef SCTC_CTC_NOSTORE
+        if (tau != 0x7fffffff) return;
+#endif
+        R* row = lat + (int64_t)tau * LP + (int64_t)K * lane;
+        if constexpr (K % 4 == 0) {
+            typename Vec<R>::v4* dst = reinterpret_cast<typename Vec<R>::v4*>(row);
+#pragma unroll
+            for (int j = 0; j < K; j += 4) dst[j / 4] = {v[j], v[j + 1], v[j + 2], v[j + 3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; ++j) row[j] = v[j];
+        }
     };
 
     R a[K];
@@ -220,19 +251,23 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
     for (int j = 0; j < K; ++j) a[j] = (R)0;
 
     double ll = 0.0;   // per-lane partial of llForward (float64 like the reference)
-    R rslot = (R)1;    // scale factor of frame tau parked in lane (tau & 63)
+    R rslot = (R)1;    // applied scale factors are parked one per lane and folded 64 at a time
+    int nscaled = 0;
     int skip = 0;
-    bool inf_cost = false;
+    // T < U: the band [start,end) is empty at every frame t >= 1 (L >= 2T+2 does not depend
+    // on t): the reference divides nothing, takes log(0) = -inf and returns cost +inf with
+    // skip False (ctc_fast.pyx:70-76 on an empty range)
+    const bool empty_band = (L >= 2 * T + 2) && T > 1;
 
     // ---- tau = 0: ctc_fast.pyx:42-47 / :79-84
-    R ycur[PF][NA];
+    RI ycur[PF][NA];
     {
-        R y0[NA];
+        RI y0[NA];
         load_frame(0, y0);
         const R yb = bcast(y0, blank);
         const R yl = gather(y0, lab[0]);
         if (lane == 0) { a[0] = yb; a[1] = yl; }
-        R c = wave_sum(a[0] + a[1]);
+        const R c = wave_sum(a[0] + a[1]);
         if (c == (R)0) {
             skip = 1;  // ZeroDivisionError at :45
         } else {
@@ -240,47 +275,48 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
             a[0] *= r;
             a[1] *= r;
             if (lane == 0) rslot = r;
+            nscaled = 1;
         }
-        typename Vec<R>::v4* dst = reinterpret_cast<typename Vec<R>::v4*>(lat + (int64_t)K * lane);
-        if constexpr (K % 4 == 0) {
-#pragma unroll
-            for (int j = 0; j < K; j += 4) dst[j / 4] = {a[j], a[j + 1], a[j + 2], a[j + 3]};
-        } else {
-#pragma unroll
-            for (int j = 0; j < K; ++j) lat[(int64_t)K * lane + j] = a[j];
-        }
+        store_row(0, a);
     }
 
-    if (!skip && T > 1) {
+    if (!skip && empty_band) {
+        R z[K];
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int tau = 1 + i;
-            if (tau < T) load_frame(tau, ycur[i]);
-            else {
+        for (int j = 0; j < K; ++j) z[j] = (R)0;
+        for (int tau = 1; tau < T; ++tau) store_row(tau, z);
+    } else if (!skip && T > 1) {
 #pragma unroll
-                for (int q = 0; q < NA; ++q) ycur[i][q] = (R)0;
-            }
-        }
+        for (int i = 0; i < PF; ++i)
+            load_frame(min(1 + i, T - 1), ycur[i]);   // unconditional (clamped): a load behind a
+                                                      // branch is waited for with vmcnt(0) at once
         for (int tb = 1; tb < T && !skip; tb += PF) {
-            R ynxt[PF][NA];
+            RI ynxt[PF][NA];
 #pragma unroll
-            for (int i = 0; i < PF; ++i) {
-                const int tau = tb + PF + i;
-                if (tau < T) load_frame(tau, ynxt[i]);
-                else {
+            for (int i = 0; i < PF; ++i) load_frame(min(tb + PF + i, T - 1), ynxt[i]);
+            // For short label rows the per-state probabilities of the whole block are gathered
+            // (ds_bpermute / readlane) before the serial part starts, so that the LDS-crossbar
+            // latency is off the recursion's dependency chain.
+            constexpr bool PREG = K <= 4;
+            R ybv[PREG ? PF : 1], ylv[PREG ? PF : 1][KH];
+            if constexpr (PREG) {
 #pragma unroll
-                    for (int q = 0; q < NA; ++q) ynxt[i][q] = (R)0;
+                for (int i = 0; i < PF; ++i) {
+                    ybv[i] = bcast(ycur[i], blank);
+#pragma unroll
+                    for (int jj = 0; jj < KH; ++jj) ylv[i][jj] = gather(ycur[i], lab[jj]);
                 }
             }
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int tau = tb + i;
                 if (tau < T && !skip) {
-                    // band limits, ctc_fast.pyx:49-54 (identical for the reversed problem)
+                    // lower band limit, ctc_fast.pyx:49-53 (identical for the reversed problem);
+                    // states >= end are exactly zero by construction
                     const int rem = 2 * (T - tau);
                     const int start = L <= rem ? 0 : L - rem;
-                    const int end = min(2 * tau + 2, L);
-                    const R yb = bcast(ycur[i], blank);
+                    R yb;
+                    if constexpr (PREG) yb = ybv[i]; else yb = bcast(ycur[i], blank);
                     const R prev_last = lane_shr1(a[K - 1]);  // state K*lane - 1
                     R n[K];
 #pragma unroll
@@ -288,51 +324,41 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
                         // blank state s = K*lane + 2*jj  (:58-62)
                         const R below = jj == 0 ? prev_last : a[2 * jj - 1];
                         const int sb = K * lane + 2 * jj;
-                        R vb = (a[2 * jj] + below) * yb;
+                        const R vb = (a[2 * jj] + below) * yb;
                         n[2 * jj] = (valid_blk[jj] && sb >= start) ? vb : (R)0;
                         // label state s = K*lane + 2*jj + 1  (:63-68)
-                        const R yl = gather(ycur[i], lab[jj]);
+                        R yl;
+                        if constexpr (PREG) yl = ylv[i][jj]; else yl = gather(ycur[i], lab[jj]);
                         R in = a[2 * jj + 1] + a[2 * jj];
-                        const R below2 = jj == 0 ? prev_last : a[2 * jj - 1];
-                        if (allow[jj]) in += below2;
-                        R vl = in * yl;
+                        if (allow[jj]) in += below;
+                        const R vl = in * yl;
                         n[2 * jj + 1] = (valid_lab[jj] && sb + 1 >= start) ? vl : (R)0;
                     }
-                    R loc = n[0];
+                    if ((tau % RS) == 0 || tau == T - 1) {
+                        // rescale (every frame when RS == 1, like :70-76); the last frame always,
+                        // so that llForward is complete
+                        R loc = n[0];
 #pragma unroll
-                    for (int j = 1; j < K; ++j) loc += n[j];
-                    const R c = wave_sum(loc);  // :71-73 (states >= end are exactly zero)
-                    if (c == (R)0) {
-                        if (start < end) {
-                            skip = 1;  // ZeroDivisionError at :75
+                        for (int j = 1; j < K; ++j) loc += n[j];
+                        const R c = wave_sum(loc);
+                        if (c == (R)0) {
+                            skip = 1;  // ZeroDivisionError at :75 (band is non-empty here)
                         } else {
-                            inf_cost = true;  // empty band: nothing divided, log(0) = -inf
+                            const R r = (R)1 / c;
 #pragma unroll
-                            for (int j = 0; j < K; ++j) a[j] = n[j];
+                            for (int j = 0; j < K; ++j) a[j] = n[j] * r;
+                            if (lane == (nscaled & 63)) rslot = r;
+                            ++nscaled;
+                            if ((nscaled & 63) == 0) {
+                                ll -= log((double)rslot);
+                                rslot = (R)1;
+                            }
                         }
                     } else {
-                        const R r = (R)1 / c;
 #pragma unroll
-                        for (int j = 0; j < K; ++j) a[j] = n[j] * r;
-                        if (lane == (tau & 63)) rslot = r;
+                        for (int j = 0; j < K; ++j) a[j] = n[j];
                     }
-                    if (!skip) {
-                        R* row = lat + (int64_t)tau * LP + (int64_t)K * lane;
-                        if constexpr (K % 4 == 0) {
-                            typename Vec<R>::v4* dst = reinterpret_cast<typename Vec<R>::v4*>(row);
-#pragma unroll
-                            for (int j = 0; j < K; j += 4)
-                                dst[j / 4] = {a[j], a[j + 1], a[j + 2], a[j + 3]};
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < K; ++j) row[j] = a[j];
-                        }
-                        // every 64 frames fold the parked scale factors into ll
-                        if ((tau & 63) == 63) {
-                            ll -= log((double)rslot);
-                            rslot = (R)1;
-                        }
-                    }
+                    if (!skip) store_row(tau, a);
                 }
             }
 #pragma unroll
@@ -341,12 +367,12 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
                 for (int q = 0; q < NA; ++q) ycur[i][q] = ynxt[i][q];
         }
     }
-    // frames whose scale factor is still parked
+    // factors still parked
     ll -= log((double)rslot);
     double total = wave_sum(ll);
     if (lane == 0) {
-        if (inf_cost) total = -INFINITY;  // math.log(0.0)
-        p.ll[2 * b + dir] = total;        // llForward (dir 0) / llBackward (dir 1)
+        if (empty_band && !skip) total = -INFINITY;  // math.log(0.0)
+        p.ll[2 * b + dir] = total;                   // llForward (dir 0) / llBackward (dir 1)
         p.skip2[2 * b + dir] = skip;
     }
 }

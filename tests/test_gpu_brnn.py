@@ -262,3 +262,38 @@ def test_brnn_update_params(mods):
     np.testing.assert_allclose(vel[0][0].copy_to_host(), 0.5 * g0, rtol=1e-6, atol=1e-7)
     n = net.grad[0][0].euclid_norm()
     assert n == pytest.approx(np.linalg.norm(g0.astype(np.float64)), rel=1e-6)
+
+
+def test_brnn_full_size_cfg3_vs_oracle(mods):
+    """the headline configuration itself (T=1000, 5x1824, A=33, U=100): two utterances through
+    the batched GPU path against the float64 oracle, plus the size-independent properties:
+    an utterance's cost does not depend on what else is in the minibatch (bit-exact), and the
+    minibatch gradient is the sum of the single-utterance gradients"""
+    _, brnnet, obrnn, torch = mods
+    D, A, H, NL, TL, T, U = 483, 33, 1824, 5, 3, 1000, 100
+    rs = np.random.RandomState(0)
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    datas = [rs.randn(D, T).astype(np.float32) for _ in range(3)]
+    labs = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(3)]
+    net = make_net(brnnet, (D, A, H, NL, TL, T), params, maxUtts=3, maxBatch=T)
+    costs, _, skips = net.costAndGradBatch(datas, labs)
+    g_all = [net.grad[i][0].copy_to_host().astype(np.float64) for i in (0, 2, NL, NL + 1, NL + 2)]
+    assert not skips.any()
+    with np.errstate(all="ignore"):
+        c_ref, g_ref, s_ref, _ = obrnn.cost_and_grad(params, datas[1].astype(np.float64), labs[1], TL, 20.0)
+    assert costs[1] == pytest.approx(c_ref, rel=1e-4)                 # north_star tolerance
+    assert abs(costs[1] - c_ref) / c_ref < 2e-6                       # what fp32 achieves here
+    # batch-composition invariance (same kernels, rows are independent)
+    c1, _, _ = net.costAndGradBatch([datas[1]], [labs[1]])
+    assert c1[0] == costs[1]
+    g1 = [net.grad[i][0].copy_to_host().astype(np.float64) for i in (0, 2, NL, NL + 1, NL + 2)]
+    for got, want in zip(g1, (g_ref["W"][0], g_ref["W"][2], g_ref["W"][NL], g_ref["Wf"], g_ref["Wb"])):
+        assert rel(got, want) < 2e-3
+    # additivity over utterances
+    acc = [g.copy() for g in g1]
+    for j in (0, 2):
+        net.costAndGradBatch([datas[j]], [labs[j]])
+        for a, i in zip(acc, (0, 2, NL, NL + 1, NL + 2)):
+            a += net.grad[i][0].copy_to_host()
+    for a, b in zip(acc, g_all):
+        assert rel(b, a) < 1e-4
