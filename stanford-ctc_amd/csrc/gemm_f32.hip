@@ -75,71 +75,6 @@ __global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmA
     const int kt_beg = blockIdx.y * per;
     const int kt_end = min(ktiles, kt_beg + per);
 
-    float4 ra[NLD], rb[NLD];
-    auto gload = [&](int kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int f = tid + NTHREADS * q;
-            if constexpr (AK) {
-                const int r = f / KQ, k = k0 + 4 * (f % KQ), row = m0 + r;
-                ra[q] = (row < M && k < K)
-                            ? *reinterpret_cast<const float4*>(p.A + (int64_t)row * p.lda + k)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                const int kr = f >> 5, k = k0 + kr, m = m0 + 4 * (f & 31);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < K && m < M) {
-                    const int64_t kk = p.idx_a ? p.idx_a[k] : k;
-                    v = *reinterpret_cast<const float4*>(p.A + kk * p.lda + m);
-                }
-                ra[q] = v;
-            }
-            if constexpr (BKC) {
-                const int r = f / KQ, k = k0 + 4 * (f % KQ), row = n0 + r;
-                rb[q] = (row < N && k < K)
-                            ? *reinterpret_cast<const float4*>(p.B + (int64_t)row * p.ldb + k)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                const int kr = f >> 5, k = k0 + kr, n = n0 + 4 * (f & 31);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < K && n < N) {
-                    const int64_t kk = p.idx_b ? p.idx_b[k] : k;
-                    v = *reinterpret_cast<const float4*>(p.B + kk * p.ldb + n);
-                }
-                rb[q] = v;
-            }
-        }
-    };
-    auto lstore = [&](int buf) {
-        float* a = As + buf * LDS_OPERAND;
-        float* b = Bs + buf * LDS_OPERAND;
-#pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int f = tid + NTHREADS * q;
-            if constexpr (AK) {
-                const int r = f / KQ, kq = 4 * (f % KQ);
-                a[(kq + 0) * LDA + r] = ra[q].x;
-                a[(kq + 1) * LDA + r] = ra[q].y;
-                a[(kq + 2) * LDA + r] = ra[q].z;
-                a[(kq + 3) * LDA + r] = ra[q].w;
-            } else {
-                const int kr = f >> 5, m = 4 * (f & 31);
-                *reinterpret_cast<float4*>(a + kr * LDA + m) = ra[q];
-            }
-            if constexpr (BKC) {
-                const int r = f / KQ, kq = 4 * (f % KQ);
-                b[(kq + 0) * LDB + r] = rb[q].x;
-                b[(kq + 1) * LDB + r] = rb[q].y;
-                b[(kq + 2) * LDB + r] = rb[q].z;
-                b[(kq + 3) * LDB + r] = rb[q].w;
-            } else {
-                const int kr = f >> 5, n = 4 * (f & 31);
-                *reinterpret_cast<float4*>(b + kr * LDB + n) = rb[q];
-            }
-        }
-    };
-
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -149,26 +84,136 @@ __global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmA
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (kt_beg < kt_end) {
+        // ---- global -> register staging.  Everything that does not depend on the K tile is
+        // hoisted out of the K loop: per-thread base pointers and, for gathered rows, the row
+        // index of the NEXT tile (fetched one tile ahead, so no load waits on a load of the same
+        // iteration).  Loads are unconditional from clamped addresses: rows/columns beyond M/N
+        // read some valid row and only feed accumulators the epilogue never stores; the K tail
+        // is zeroed when the tile goes to LDS.  (A load behind a divergent branch costs an
+        // exec-mask branch plus an early s_waitcnt, a select right behind the load a vmcnt(0).)
+        float4 ra[NLD], rb[NLD];
+        const float* pa[NLD];
+        const float* pb[NLD];
+        int ia[NLD], ib[NLD];   // row-contiguous operands: (gathered) row of the next tile
+        const int Kc4 = (K - 1) & ~3, Kc1 = K - 1;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int f = tid + NTHREADS * q;
+            if constexpr (AK) {
+                pa[q] = p.A + (int64_t)min(m0 + f / KQ, M - 1) * p.lda;
+            } else {
+                pa[q] = p.A + min(m0 + 4 * (f & 31), (M - 1) & ~3);
+                const int k = min(kt_beg * BK + (f >> 5), Kc1);
+                ia[q] = p.idx_a ? p.idx_a[k] : k;
+            }
+            if constexpr (BKC) {
+                pb[q] = p.B + (int64_t)min(n0 + f / KQ, N - 1) * p.ldb;
+            } else {
+                pb[q] = p.B + min(n0 + 4 * (f & 31), (N - 1) & ~3);
+                const int k = min(kt_beg * BK + (f >> 5), Kc1);
+                ib[q] = p.idx_b ? p.idx_b[k] : k;
+            }
+        }
+        auto gload = [&](int kt) {
+            const int k0 = kt * BK;
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) {
+                const int f = tid + NTHREADS * q;
+                if constexpr (AK) {
+                    ra[q] = *reinterpret_cast<const float4*>(pa[q] + min(k0 + 4 * (f % KQ), Kc4));
+                } else {
+                    ra[q] = *reinterpret_cast<const float4*>(pa[q] + (uint32_t)ia[q] * (uint32_t)p.lda);
+                    const int kn = min(k0 + BK + (f >> 5), Kc1);
+                    ia[q] = p.idx_a ? p.idx_a[kn] : kn;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) {
+                const int f = tid + NTHREADS * q;
+                if constexpr (BKC) {
+                    rb[q] = *reinterpret_cast<const float4*>(pb[q] + min(k0 + 4 * (f % KQ), Kc4));
+                } else {
+                    rb[q] = *reinterpret_cast<const float4*>(pb[q] + (uint32_t)ib[q] * (uint32_t)p.ldb);
+                    const int kn = min(k0 + BK + (f >> 5), Kc1);
+                    ib[q] = p.idx_b ? p.idx_b[kn] : kn;
+                }
+            }
+        };
+        auto zero_tail = [&](float4& v, int k) {   // component-wise: a struct select goes via scratch
+            const bool ok = k < K;
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        };
+        // registers -> LDS tile `buf` of K tile kt; the A and B halves are separate so that they
+        // can be slotted between different MFMA groups
+        auto lstore_a = [&](int buf, int kt) {
+            float* a = As + buf * LDS_OPERAND;
+            const bool tail = (kt + 1) * BK > K;   // uniform
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) {
+                const int f = tid + NTHREADS * q;
+                if constexpr (AK) {
+                    const int r = f / KQ, kq = 4 * (f % KQ);
+                    if (tail) zero_tail(ra[q], kt * BK + kq);
+                    a[(kq + 0) * LDA + r] = ra[q].x;
+                    a[(kq + 1) * LDA + r] = ra[q].y;
+                    a[(kq + 2) * LDA + r] = ra[q].z;
+                    a[(kq + 3) * LDA + r] = ra[q].w;
+                } else {
+                    const int kr = f >> 5, m = 4 * (f & 31);
+                    if (tail) zero_tail(ra[q], kt * BK + kr);
+                    *reinterpret_cast<float4*>(a + kr * LDA + m) = ra[q];
+                }
+            }
+        };
+        auto lstore_b = [&](int buf, int kt) {
+            float* b = Bs + buf * LDS_OPERAND;
+            const bool tail = (kt + 1) * BK > K;
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) {
+                const int f = tid + NTHREADS * q;
+                if constexpr (BKC) {
+                    const int r = f / KQ, kq = 4 * (f % KQ);
+                    if (tail) zero_tail(rb[q], kt * BK + kq);
+                    b[(kq + 0) * LDB + r] = rb[q].x;
+                    b[(kq + 1) * LDB + r] = rb[q].y;
+                    b[(kq + 2) * LDB + r] = rb[q].z;
+                    b[(kq + 3) * LDB + r] = rb[q].w;
+                } else {
+                    const int kr = f >> 5, n = 4 * (f & 31);
+                    if (tail) zero_tail(rb[q], kt * BK + kr);
+                    *reinterpret_cast<float4*>(b + kr * LDB + n) = rb[q];
+                }
+            }
+        };
+
         gload(kt_beg);
-        lstore(0);
+        lstore_a(0, kt_beg);
+        lstore_b(0, kt_beg);
         __syncthreads();
         int buf = 0;
         const int kh = lane >> 5, li = lane & 31;
+        constexpr int NSTEP = BK / 2;
         for (int kt = kt_beg; kt < kt_end; ++kt) {
             const bool more = kt + 1 < kt_end;
-            if (more) gload(kt + 1);
+#ifdef SCTC_GEMM_STAMP
+            const bool st_on = p.splitk_ws && p.splits == 1 && blockIdx.x == 8 && tid == 0 &&
+                               kt >= kt_beg + 16 && kt < kt_beg + 32;
+            unsigned* st_out = reinterpret_cast<unsigned*>(p.splitk_ws) + (kt - kt_beg - 16) * 8;
+            if (st_on) st_out[0] = (unsigned)clock64();
+#endif
             const float* a = As + buf * LDS_OPERAND + kh * LDA + wm * 64 + li;
             const float* b = Bs + buf * LDS_OPERAND + kh * LDB + wn * 64 + li;
-            // fragments of step kk+2 are requested from LDS before the MFMAs of step kk issue,
-            // so the ~100-cycle ds_read latency hides under 4 x 64 cycles of matrix work
+            // Software pipeline inside one K tile (NSTEP groups of 4 MFMAs = 256 matrix-pipe
+            // cycles each).  Everything that is not an MFMA is slotted BEHIND a group so that it
+            // issues in that group's shadow: the LDS fragments of group s+1 behind group s-... ,
+            // the global loads of tile kt+1 behind group 0, its LDS stores behind the last
+            // groups (the data has had >= NSTEP-3 groups to arrive).
             float a0 = a[0], a1 = a[32], b0 = b[0], b1 = b[32];
-#ifdef SCTC_GEMM_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
+            for (int s = 0; s < NSTEP; ++s) {
+                const int kk = 2 * s;
                 float a0n = 0.f, a1n = 0.f, b0n = 0.f, b1n = 0.f;
-                if (kk + 2 < BK) {
+                if (s + 1 < NSTEP) {
                     a0n = a[(kk + 2) * LDA];
                     a1n = a[(kk + 2) * LDA + 32];
                     b0n = b[(kk + 2) * LDB];
@@ -180,12 +225,20 @@ __global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmA
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
                 a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
+                if (more) {
+                    if (s == 0) { __builtin_amdgcn_sched_barrier(0); gload(kt + 1); }
+                    if (s == NSTEP - 3) { __builtin_amdgcn_sched_barrier(0); lstore_a(buf ^ 1, kt + 1); }
+                    if (s == NSTEP - 2) { __builtin_amdgcn_sched_barrier(0); lstore_b(buf ^ 1, kt + 1); }
+                }
             }
-#ifdef SCTC_GEMM_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
+#ifdef SCTC_GEMM_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (st_on) st_out[3] = (unsigned)clock64();
 #endif
-            if (more) lstore(buf ^ 1);
             __syncthreads();
+#ifdef SCTC_GEMM_STAMP
+            if (st_on) st_out[4] = (unsigned)clock64();
+#endif
             buf ^= 1;
         }
     }
@@ -333,6 +386,9 @@ extern "C" int sctc_gemm_f32(const float* A_dev, int64_t lda, int32_t a_kcontig,
         g.splitk_ws = (float*)workspace_dev;
     } else {
         g.splits = 1;
+#ifdef SCTC_GEMM_STAMP
+        g.splitk_ws = (float*)workspace_dev;   // diagnostics build: timeline stamps land here
+#endif
     }
     return launch_gemm_f32(g, (hipStream_t)stream);
 }

@@ -109,6 +109,28 @@ def sec_gemm3():
         del a, b, c
 
 
+def sec_gemmstamp():
+    """per-K-tile timeline of one GEMM block (needs a library built with -DSCTC_GEMM_STAMP)"""
+    L = _sctc.lib()
+    for (M, N, K, akc, bkc, tag) in ((32000, 1920, 1824, 1, 1, "NT"), (32000, 1920, 1824, 1, 0, "NN"),
+                                     (1920, 1920, 4096, 0, 0, "TN")):
+        a = torch.randn((M, K) if akc else (K, M), device="cuda")
+        b = torch.randn((N, K) if bkc else (K, N), device="cuda")
+        c = torch.empty((M, N), device="cuda")
+        ws = torch.zeros(4096, dtype=torch.int32, device="cuda")
+        # a tiny workspace: too small for split-K, so splits stays 1 and the stamps land in it
+        for _ in range(3):
+            rc = L.sctc_gemm_f32(a.data_ptr(), a.shape[1], akc, b.data_ptr(), b.shape[1], bkc,
+                                 c.data_ptr(), N, M, N, K, None, 0, ws.data_ptr(), 0, None)
+            assert rc == 0
+        torch.cuda.synchronize()
+        st = ws.cpu().numpy()[:16 * 8].reshape(16, 8).astype(np.int64)
+        d = np.diff(st[:, :5], axis=1) & 0xffffffff
+        per = np.diff(st[:, 0]) & 0xffffffff
+        print("gemm %s: cycles per K tile median %d | gload-issue %d, lds-read+mfma %d, lds-store %d, barrier %d" %
+              ((tag, np.median(per)) + tuple(np.median(d, axis=0))))
+
+
 def sec_ctc():
     import ctc_fast
     rs = np.random.RandomState(0)
@@ -196,7 +218,7 @@ def sec_recdbg(sync=0):
 
 def main():
     want = sys.argv[1:] or ["info", "gemm", "ctc", "brnn"]
-    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "ctc": sec_ctc,
+    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "gemmstamp": sec_gemmstamp, "ctc": sec_ctc,
              "brnn": lambda: sec_brnn("cfg3", 32, 0),
              "brnn1": lambda: sec_brnn("cfg3", 32, 1),
              "recdbg": lambda: sec_recdbg(0), "recdbg1": lambda: sec_recdbg(1),
