@@ -183,6 +183,32 @@ def main():
             "phase_ms": ph,
             "cost_mean": float(np.mean(cost[~skip])) if (~skip).any() else None,
         }
+        # ---- side measurements (never `value`): SURVEY 8(d) defines the metric from pinned host
+        # features, and asks for a second run with ragged lengths T_b ~ U[0.5T, T]
+        host_feats = torch.empty(B * T, D, dtype=torch.float32).pin_memory()
+        host_feats.copy_(feats)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            net.costAndGradBatch(None, labels, feats_dev=host_feats.cuda(non_blocking=True), T_b=Ts)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        out["pcie_inclusive"] = {"value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
+                                 "h2d_bytes_per_step": B * T * D * 4,
+                                 "note": "features start in pinned host memory; H2D inside the timed region"}
+        Tr = sorted((int(t) for t in rs.randint(T // 2, T + 1, size=B)), reverse=True)
+        lab_r = [l[:max(1, t // 10)] for l, t in zip(labels, Tr)]
+        feats_r = feats[:sum(Tr)]
+        net.costAndGradBatch(None, lab_r, feats_dev=feats_r, T_b=Tr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            net.costAndGradBatch(None, lab_r, feats_dev=feats_r, T_b=Tr)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        out["ragged"] = {"value": sum(Tr) / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
+                         "frames_per_step": sum(Tr),
+                         "note": "T_b ~ U[T/2, T] sorted descending, U_b = T_b/10, same net"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
     if world > 1:

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmA
             const bool st_on = p.splitk_ws && p.splits == 1 && blockIdx.x == 8 && tid == 0 &&
                                kt >= kt_beg + 16 && kt < kt_beg + 32;
             unsigned* st_out = reinterpret_cast<unsigned*>(p.splitk_ws) + (kt - kt_beg - 16) * 8;
-            if (st_on) st_out[0] = (unsigned)clock64();
+            if (st_on) { st_out[0] = (unsigned)clock64(); st_out[5] = (unsigned)wall_clock64(); }
 #endif
             const float* a = As + buf * LDS_OPERAND + kh * LDA + wm * 64 + li;
             const float* b = Bs + buf * LDS_OPERAND + kh * LDB + wn * 64 + li;

@@ -33,13 +33,14 @@ struct RecArgs {
     float* xbuf;
     const int32_t* xbase;   // device [Tmax]
     int32_t n_xrows;
-    unsigned* counters;     // [REC_COUNTER_WORDS]: error word at [2], per-producer step flags at [4..260)
+    unsigned* counters;     // [REC_COUNTER_WORDS]: error word at [2], per-producer step flags from [4]
     int32_t sync_mode;      // 0: plain exchange stores + agent-scope release fence before the flag
                             // 1: write-through (sc1) exchange stores, no fence
+    int32_t variant;        // 0: pick automatically; 1: force the one-workgroup-per-CU kernel
     unsigned* debug;        // nullable: s_memtime stamps [2 wgs][16 steps][8] for steps 64..79
 };
 static constexpr int REC_DEBUG_WORDS = 2 * 16 * 8;
-static constexpr int REC_COUNTER_WORDS = 4 + 256;
+static constexpr int REC_COUNTER_WORDS = 4 + 4 * 128;   // error word + up to 4 chains x 128 producers
 
 // exchange rows needed for `rows` frames spread over `tmax` time steps (worst case)
 static inline int64_t recurrent_xrows_bound(int64_t rows, int64_t tmax) { return rows + 3 * tmax; }

@@ -36,6 +36,7 @@
 
 namespace sctc {
 
+typedef void (*RecKernel)(RecArgs);
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -316,6 +317,169 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Two-chains-per-CU variant (17..32 utterances).  One step of the kernel above is a serial
+// chain: flags -> exchange loads (a fabric round trip) -> MFMAs -> reduce -> stores -> flag;
+// the matrix pipes idle during everything but the MFMAs.  Different utterances never interact,
+// so the minibatch splits into independent chains of 16 utterances.  Here a workgroup owns
+// 16 output units x ONE utterance tile, and two workgroups (of different chains) share a CU:
+// while one waits for its exchange the other one computes.  Per workgroup: 4 waves = 4 K
+// quarters (the 114 chunks of H = 1824 split 29/29/28/28); the 16 x H weight slab no longer
+// fits twice into 160 KiB of LDS, so each wave keeps NREG of its chunks in registers and the
+// rest in a wave-private LDS region.  Exchange traffic per CU and step is unchanged (2 x 16
+// utterances), flags are per chain: counters[4 + chain*128 + wg].
+template <int NCQ, int NREG>
+__global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    constexpr int NLDS = NCQ - NREG;        // chunks per wave held in LDS
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Hp = p.Hp, nch = Hp >> 4, nwg = nch;
+    const int chain = blockIdx.x / nwg, wg = blockIdx.x - chain * nwg;
+    const int g = chain & 1, tile = chain >> 1;
+    const int row0 = wg * 16;
+    const int uj = lane & 15, kq = lane >> 4;
+    const int sync_mode = p.sync_mode;
+    // K split: `base` chunks per wave, the first `rem` waves take one more
+    const int base = nch >> 2, rem = nch & 3;
+    const int cnt = base + (wave < rem ? 1 : 0);
+    const int c_beg = wave * base + min(wave, rem);
+    float4* Wl = lds4 + (size_t)wave * NLDS * 64;     // [NLDS][64] wave-private, fragment order
+    float4* red = lds4 + (size_t)4 * NLDS * 64;       // [3][64] partial sums of waves 1..3
+
+    // ---- stationary weights: fragment of chunk c = { Wop[row0 + (lane&15)][16c + 4*(lane>>4) + q] }_q
+    auto load_w = [&](int c) {
+        const float* W = p.W[g];
+        float4 v;
+        if (!p.transpose) {
+            v = *reinterpret_cast<const float4*>(W + (int64_t)(row0 + uj) * p.ldw + 16 * c + 4 * kq);
+        } else {
+            const float* col = W + (int64_t)(16 * c + 4 * kq) * p.ldw + row0 + uj;
+            v.x = col[0];
+            v.y = col[p.ldw];
+            v.z = col[2 * p.ldw];
+            v.w = col[3 * p.ldw];
+        }
+        return v;
+    };
+    float4 wreg[NREG > 0 ? NREG : 1];
+#pragma unroll
+    for (int u = 0; u < NREG; ++u) wreg[u] = load_w(c_beg + min(u, cnt - 1));
+#pragma unroll 4
+    for (int u = NREG; u < NCQ; ++u) Wl[(u - NREG) * 64 + lane] = load_w(c_beg + min(u, cnt - 1));
+    __syncthreads();
+
+    const bool desc = p.descending[g] != 0;
+    const float* pre = p.pre[g];
+    const float* act = p.act[g];
+    float* out = p.out[g];
+    const int64_t ld = p.ld;
+    const float hi = p.max_act > 0.f ? p.max_act : INFINITY;
+    unsigned* flags = p.counters + 4 + chain * 128;
+    unsigned* err = p.counters + 2;
+    const unsigned chunk_stride = (unsigned)p.n_xrows * 64u;
+    float* xg = p.xbuf + (size_t)g * p.n_xrows * Hp;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        xg, 0, (int)((size_t)p.n_xrows * Hp * sizeof(float)), 0x00020000);
+
+    const int ub = tile * 16 + uj;
+    const int uT = ub < p.B ? p.T_b[ub] : 0;
+    // this chain is finished once its longest utterance (the tile's first) is
+    const int Tchain = tile * 16 < p.B ? p.T_b[tile * 16] : 0;
+
+    const int dbg_sel = (p.debug && chain == 0 && tid == 0) ? (wg == 0 ? 0 : (wg == nwg - 1 ? 1 : -1)) : -1;
+    auto stamp = [&](int j, int k) {
+        if (dbg_sel >= 0 && j >= 64 && j < 80)
+            p.debug[(dbg_sel * 16 + (j - 64)) * 8 + k] = (unsigned)clock64();
+    };
+
+    // rowbase / xbase of a step are fetched one step ahead: three dependent L2 round trips at
+    // the head of every step would otherwise sit on the recurrence's critical path
+    int rb_next = uT > 0 ? p.rowbase[desc ? uT - 1 : 0] : 0;
+    int xb_next = p.xbase[0], xb_cur = 0;
+    for (int j = 0; j < Tchain; ++j) {
+        stamp(j, 0);
+        f32x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = {0.f, 0.f, 0.f, 0.f};
+        const bool active = j < uT;
+        const int xb_prev = xb_cur;
+        const int rb = rb_next;
+        xb_cur = xb_next;
+        {
+            const int jn = min(j + 1, Tchain - 1);
+            const int tn = desc ? uT - 1 - jn : jn;
+            rb_next = p.rowbase[min(max(tn, 0), p.Tmax - 1)];
+            xb_next = p.xbase[jn];
+        }
+        const int64_t orow = active ? (int64_t)rb + ub : 0;
+        const unsigned xrow = active ? (unsigned)xb_cur + (unsigned)ub : 0u;
+        const unsigned prow = (active && j > 0) ? (unsigned)xb_prev + (unsigned)ub : 0u;
+        const unsigned xin = prow * 64u + (unsigned)kq * 16u;
+        const unsigned xout = xrow * 64u + (unsigned)kq * 16u;
+        float4 pre4 = make_float4(0.f, 0.f, 0.f, 0.f), act4 = pre4;
+        if (wave == 0 && active) {
+            pre4 = *reinterpret_cast<const float4*>(pre + orow * ld + row0 + 4 * kq);
+            if (act) act4 = *reinterpret_cast<const float4*>(act + orow * ld + row0 + 4 * kq);
+        }
+
+        if (j > 0) {
+            wait_all(flags, nwg, (unsigned)j, err);
+            stamp(j, 1);
+            float4 x[NCQ];
+#pragma unroll
+            for (int u = 0; u < NCQ; ++u)
+                x[u] = ld_x(xrsrc, xin, (unsigned)(c_beg + min(u, cnt - 1)) * chunk_stride);
+            __builtin_amdgcn_sched_barrier(0);   // every load ahead of the first MFMA
+#pragma unroll
+            for (int u = 0; u < NCQ; ++u) {
+                if (u < NCQ - 1 || cnt == NCQ) {   // the last chunk exists only in the longer waves
+                    const float4 a = u < NREG ? wreg[u < NREG ? u : 0] : Wl[(u - NREG) * 64 + lane];
+                    SCTC_MFMA4(acc, a, x[u])
+                }
+            }
+            if (p.debug) {
+                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+                stamp(j, 2);
+            }
+            if (wave != 0) {
+                const f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                red[(wave - 1) * 64 + lane] = make_float4(s[0], s[1], s[2], s[3]);
+            }
+            __syncthreads();
+            stamp(j, 3);
+        }
+
+        if (wave == 0 && active) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j > 0) {
+                const float4 r1 = red[lane], r2 = red[64 + lane], r3 = red[128 + lane];
+                const f32x4 q = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                s = make_float4((q[0] + r1.x) + (r2.x + r3.x), (q[1] + r1.y) + (r2.y + r3.y),
+                                (q[2] + r1.z) + (r2.z + r3.z), (q[3] + r1.w) + (r2.w + r3.w));
+            }
+            float4 o;
+            if (!act) {
+                o.x = fminf(fmaxf(pre4.x + s.x, 0.f), hi);
+                o.y = fminf(fmaxf(pre4.y + s.y, 0.f), hi);
+                o.z = fminf(fmaxf(pre4.z + s.z, 0.f), hi);
+                o.w = fminf(fmaxf(pre4.w + s.w, 0.f), hi);
+            } else {
+                o.x = (act4.x > 0.f && act4.x < hi) ? pre4.x + s.x : 0.f;
+                o.y = (act4.y > 0.f && act4.y < hi) ? pre4.y + s.y : 0.f;
+                o.z = (act4.z > 0.f && act4.z < hi) ? pre4.z + s.z : 0.f;
+                o.w = (act4.w > 0.f && act4.w < hi) ? pre4.w + s.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(out + orow * ld + row0 + 4 * kq) = o;
+            st_x(xrsrc, xout, (unsigned)wg * chunk_stride, o, sync_mode);
+        }
+        stamp(j, 4);
+        if (j + 1 < Tchain) publish_step(flags + wg, (unsigned)(j + 1), sync_mode);
+        stamp(j, 5);
+    }
+}
+
 size_t recurrent_xbuf_floats(int Hp, int64_t max_xrows)
 {
     return (size_t)2 * (size_t)max_xrows * Hp;  // one chunk-major state copy per direction
@@ -332,8 +496,6 @@ int recurrent_supported(int Hp, int B, char* why, int why_len)
     if (B > 128) { snprintf(why, why_len, "minibatch %d > 128 utterances per launch", B); return 0; }
     return 1;
 }
-
-typedef void (*RecKernel)(RecArgs);
 
 template <int NTW>
 static RecKernel pick_kernel(int nch_half)
@@ -364,9 +526,29 @@ int launch_recurrent(const RecArgs& a, hipStream_t stream)
         return set_error(SCTC_ERR_ARG, "recurrent kernel: needs %d co-resident workgroups, device "
                          "has %d CUs", 2 * nwg, cus);
     const int ntiles = (a.B + 15) / 16;
+    SCTC_HIP_TRY(hipMemsetAsync(a.counters, 0, REC_COUNTER_WORDS * sizeof(unsigned), stream));
+    if (ntiles == 2 && a.variant != 1 && 4 * nwg <= 2 * cus) {
+        // two chains per CU; NREG keeps the LDS share of the slab at <= 76 KiB per workgroup
+        RecKernel qk = nullptr;
+        int ncq = 0, nreg = 0;
+        switch (nwg) {
+            case 32:  qk = brnn_recurrent_q_kernel<8, 0>;   ncq = 8;  nreg = 0;  break;  // H = 512
+            case 64:  qk = brnn_recurrent_q_kernel<16, 0>;  ncq = 16; nreg = 0;  break;  // H = 1024
+            case 114: qk = brnn_recurrent_q_kernel<29, 10>; ncq = 29; nreg = 10; break;  // H = 1824
+            case 128: qk = brnn_recurrent_q_kernel<32, 13>; ncq = 32; nreg = 13; break;  // H = 2048
+            default: break;
+        }
+        if (qk) {
+            const size_t smem = sizeof(float4) * ((size_t)4 * (ncq - nreg) * 64 + 3 * 64);
+            SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(qk, dim3(4 * nwg), dim3(256), smem, stream, a);
+            SCTC_HIP_TRY(hipGetLastError());
+            return SCTC_OK;
+        }
+    }
     const int ntw = ntiles <= 2 ? 1 : (ntiles <= 4 ? 2 : 4);
     const size_t smem = sizeof(float4) * ((size_t)nwg * 64 + 2 * ntw * 64);
-    SCTC_HIP_TRY(hipMemsetAsync(a.counters, 0, REC_COUNTER_WORDS * sizeof(unsigned), stream));
     RecKernel kern = ntw == 1 ? pick_kernel<1>(nwg / 2)
                      : (ntw == 2 ? pick_kernel<2>(nwg / 2) : pick_kernel<4>(nwg / 2));
     SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -109,6 +109,25 @@ def sec_gemm3():
         del a, b, c
 
 
+def sec_gemmk():
+    """time vs K at fixed M x N: the intercept is the per-block fixed cost (prologue+epilogue)"""
+    L = _sctc.lib()
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    for (M, N) in ((32768, 1536), (32000, 1824), (32000, 1792)):
+        for K in (64, 256, 512, 1024, 2048, 4096, 8192):
+            a = torch.randn((M, K), device="cuda")
+            b = torch.randn((N, K), device="cuda")
+            c = torch.empty((M, N), device="cuda")
+
+            def run():
+                rc = L.sctc_gemm_f32(a.data_ptr(), K, 1, b.data_ptr(), K, 1,
+                                     c.data_ptr(), N, M, N, K, None, 0, ws.data_ptr(), ws.numel(), None)
+                assert rc == 0, L.sctc_last_error()
+            ms = timed(run)
+            print("gemmk M=%d N=%d K=%5d: %.3f ms  %.1f TFLOP/s" % (M, N, K, ms, 2.0 * M * N * K / ms / 1e9))
+            del a, b, c
+
+
 def sec_gemmstamp():
     """per-K-tile timeline of one GEMM block (needs a library built with -DSCTC_GEMM_STAMP)"""
     L = _sctc.lib()
@@ -125,10 +144,13 @@ def sec_gemmstamp():
             assert rc == 0
         torch.cuda.synchronize()
         st = ws.cpu().numpy()[:16 * 8].reshape(16, 8).astype(np.int64)
-        d = np.diff(st[:, :5], axis=1) & 0xffffffff
         per = np.diff(st[:, 0]) & 0xffffffff
-        print("gemm %s: cycles per K tile median %d | gload-issue %d, lds-read+mfma %d, lds-store %d, barrier %d" %
-              ((tag, np.median(per)) + tuple(np.median(d, axis=0))))
+        wall = np.diff(st[:, 5]) & 0xffffffff            # 100 MHz constant clock
+        mhz = 100.0 * per.sum() / max(1, wall.sum())
+        print("gemm %s: shader cycles per K tile median %d (ideal 6144 = 3 waves x 32 MFMA x 64) | "
+              "mfma+interleaved %d, barrier %d | shader clock under load ~%.0f MHz" %
+              (tag, np.median(per), np.median((st[:, 3] - st[:, 0]) & 0xffffffff),
+               np.median((st[:, 4] - st[:, 3]) & 0xffffffff), mhz))
 
 
 def sec_ctc():
@@ -218,7 +240,7 @@ def sec_recdbg(sync=0):
 
 def main():
     want = sys.argv[1:] or ["info", "gemm", "ctc", "brnn"]
-    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "gemmstamp": sec_gemmstamp, "ctc": sec_ctc,
+    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "gemmstamp": sec_gemmstamp, "gemmk": sec_gemmk, "ctc": sec_ctc,
              "brnn": lambda: sec_brnn("cfg3", 32, 0),
              "brnn1": lambda: sec_brnn("cfg3", 32, 1),
              "recdbg": lambda: sec_recdbg(0), "recdbg1": lambda: sec_recdbg(1),

@@ -297,3 +297,63 @@ def test_brnn_full_size_cfg3_vs_oracle(mods):
             a += net.grad[i][0].copy_to_host()
     for a, b in zip(acc, g_all):
         assert rel(b, a) < 1e-4
+
+
+def _all_grads(net, NL):
+    return [net.grad[i][0].copy_to_host().astype(np.float64).copy() for i in range(NL + 3)]
+
+
+def test_recurrent_two_chain_kernel_vs_oracle(mods, monkeypatch):
+    """17..32 utterances run the two-chains-per-CU recurrent kernel (recurrent.hip): ragged
+    minibatch of 24 at H=512 against the float64 oracle, and against the one-workgroup-per-CU
+    kernel (SCTC_REC_VARIANT=1) on the same inputs"""
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(11)
+    D, A, H, NL, TL = 40, 33, 512, 2, 1
+    Ts = [int(t) for t in rs.randint(3, 41, size=24)]
+    Ts[5] = 40
+    Ts[17] = 1
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 8)).astype(np.int32) for T in Ts]
+    with np.errstate(all="ignore"):
+        costs_ref, g_ref, skips_ref, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+    net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=len(Ts))
+    costs, _, skips = net.costAndGradBatch(datas, labs)
+    np.testing.assert_array_equal(skips, skips_ref)
+    np.testing.assert_allclose(costs[~skips_ref], costs_ref[~skips_ref], rtol=1e-4)
+    check_grads(net, g_ref, NL)
+    g_q = _all_grads(net, NL)
+    monkeypatch.setenv("SCTC_REC_VARIANT", "1")
+    net1 = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=len(Ts))
+    costs1, _, _ = net1.costAndGradBatch(datas, labs)
+    np.testing.assert_allclose(costs, costs1, rtol=1e-6)
+    for a, b in zip(g_q, _all_grads(net1, NL)):
+        assert rel(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("H", [1824, 2048, 1024])
+def test_recurrent_two_chain_kernel_layer_sizes(mods, monkeypatch, H):
+    """the register/LDS weight split (H=1824: 29/29/28/28 chunks per wave, 10 in registers;
+    H=2048: 32 per wave, 13 in registers) against the one-workgroup-per-CU kernel"""
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(H)
+    D, A, NL, TL = 32, 33, 2, 1
+    Ts = sorted((int(t) for t in rs.randint(8, 25, size=32)), reverse=True)
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 8)).astype(np.int32) for T in Ts]
+    net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=len(Ts))
+    costs, _, skips = net.costAndGradBatch(datas, labs)
+    assert not skips.any()
+    g_q = _all_grads(net, NL)
+    monkeypatch.setenv("SCTC_REC_VARIANT", "1")
+    net1 = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=len(Ts))
+    costs1, _, _ = net1.costAndGradBatch(datas, labs)
+    np.testing.assert_allclose(costs, costs1, rtol=1e-5)
+    for a, b in zip(g_q, _all_grads(net1, NL)):
+        assert rel(a, b) < 1e-4
+    # one utterance of the minibatch against the oracle
+    with np.errstate(all="ignore"):
+        c_ref, _, _, _ = obrnn.cost_and_grad(params, datas[20], labs[20], TL, 20.0)
+    assert costs[20] == pytest.approx(c_ref, rel=1e-4)
