@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the PCIe-inclusive and ragged side measurements (profiling runs)")
     ap.add_argument("--batch", type=int, default=CFG["B"], help="utterances per GPU")
     args = ap.parse_args()
 
@@ -185,30 +187,31 @@ def main():
         }
         # ---- side measurements (never `value`): SURVEY 8(d) defines the metric from pinned host
         # features, and asks for a second run with ragged lengths T_b ~ U[0.5T, T]
-        host_feats = torch.empty(B * T, D, dtype=torch.float32).pin_memory()
-        host_feats.copy_(feats)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            net.costAndGradBatch(None, labels, feats_dev=host_feats.cuda(non_blocking=True), T_b=Ts)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 3
-        out["pcie_inclusive"] = {"value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
-                                 "h2d_bytes_per_step": B * T * D * 4,
-                                 "note": "features start in pinned host memory; H2D inside the timed region"}
-        Tr = sorted((int(t) for t in rs.randint(T // 2, T + 1, size=B)), reverse=True)
-        lab_r = [l[:max(1, t // 10)] for l, t in zip(labels, Tr)]
-        feats_r = feats[:sum(Tr)]
-        net.costAndGradBatch(None, lab_r, feats_dev=feats_r, T_b=Tr)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            net.costAndGradBatch(None, lab_r, feats_dev=feats_r, T_b=Tr)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 3
-        out["ragged"] = {"value": sum(Tr) / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
-                         "frames_per_step": sum(Tr),
-                         "note": "T_b ~ U[T/2, T] sorted descending, U_b = T_b/10, same net"}
+        # HBM-side traffic and MFMA-busy counters cannot be sampled from inside this process:
+        # they come from the committed rocprofv3 --pmc passes of this same command
+        # (tools/profile_bench.sh -> profiles/*_pmc_summary.json), labelled as such
+        pmc = load_pmc_summary()
+        if pmc:
+            g = pmc["kernels"].get("gemm_f32_kernel", {})
+            if "fetch_bytes_x2" in g and "write_bytes" in g:
+                out["roofline"]["traffic"] = g["fetch_bytes_x2"] + g["write_bytes"]
+                out["roofline"]["traffic_note"] = (
+                    "mean per gemm_f32_kernel launch, rocprofv3 FETCH_SIZE x2 (gfx950 wide-load "
+                    "correction) + WRITE_SIZE from %s; algorithmic operand bytes per launch: %.3g"
+                    % (pmc["_file"], gemm_operand_bytes(cfg) / n_gemm_launches))
+            if "mfma_util" in g:
+                out["roofline"]["mfma_util_pmc"] = g["mfma_util"]
+            r = pmc["kernels"].get("brnn_recurrent", {})
+            if "mfma_util" in r:
+                out["roofline_recurrent"]["mfma_util_pmc"] = r["mfma_util"]
+            c = pmc["kernels"]
+            if all(k in c and "fetch_bytes" in c[k] and "write_bytes" in c[k]
+                   for k in ("softmax_rows_kernel", "ctc_lattice_kernel", "ctc_grad_kernel")):
+                out["roofline_ctc"]["traffic"] = sum(
+                    c[k]["fetch_bytes"] + c[k]["write_bytes"]
+                    for k in ("softmax_rows_kernel", "ctc_lattice_kernel", "ctc_grad_kernel"))
+        if not args.no_side:
+            side_measurements(out, net, feats, labels, Ts, rs, torch, B, T, D)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
     if world > 1:
@@ -216,6 +219,66 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def load_pmc_summary():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        d["_file"] = os.path.relpath(files[-1], ROOT)
+        return d
+    except Exception:
+        return None
+
+
+def gemm_operand_bytes(cfg):
+    """algorithmic bytes the time-batched GEMMs of one step must move once: every operand and
+    result matrix read/written one time (fwd, dgrad, wgrad, recurrent wgrad), fp32"""
+    D, A, H, NL, T, B = (cfg[k] for k in ("D", "A", "H", "NL", "T", "B"))
+    rows = B * T
+    dims = [D] + [H] * NL + [A]
+    total = 0
+    for i in range(NL + 1):
+        m, n = dims[i + 1], dims[i]
+        total += (rows * n + m * n + rows * m)            # fwd: X, W -> Z
+        total += (rows * m + rows * n + m * n)            # wgrad: delta, X -> dW
+        if i > 0:
+            total += (rows * m + m * n + rows * n)        # dgrad: delta, W -> dX
+    total += 2 * (2 * rows * H + H * H)                   # recurrent wgrads
+    return 4 * total
+
+
+def side_measurements(out, net, feats, labels, Ts, rs, torch, B, T, D):
+    """never `value`: the PCIe-inclusive rate (features start in pinned host memory) and the
+    ragged-minibatch rate SURVEY 8(d) asks for beside the headline"""
+    host_feats = torch.empty(B * T, D, dtype=torch.float32).pin_memory()
+    host_feats.copy_(feats)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        net.costAndGradBatch(None, labels, feats_dev=host_feats.cuda(non_blocking=True), T_b=Ts)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    out["pcie_inclusive"] = {"value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
+                             "h2d_bytes_per_step": B * T * D * 4,
+                             "note": "features start in pinned host memory; H2D inside the timed region"}
+    Tr = sorted((int(t) for t in rs.randint(T // 2, T + 1, size=B)), reverse=True)
+    lab_r = [l[:max(1, t // 10)] for l, t in zip(labels, Tr)]
+    feats_r = feats[:sum(Tr)]
+    net.costAndGradBatch(None, lab_r, feats_dev=feats_r, T_b=Tr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        net.costAndGradBatch(None, lab_r, feats_dev=feats_r, T_b=Tr)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    out["ragged"] = {"value": sum(Tr) / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
+                     "frames_per_step": sum(Tr),
+                     "note": "T_b ~ U[T/2, T] sorted descending, U_b = T_b/10, same net"}
 
 
 if __name__ == "__main__":

@@ -29,12 +29,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SCTC_GEMM_OCC
 #define SCTC_GEMM_OCC 3
 #endif
-static constexpr int BM = 128, BN = 128, BK = SCTC_GEMM_BK, NTHREADS = 256;
-static constexpr int KQ = BK / 4;                    // float4 per row of a K-contiguous operand tile
-static constexpr int NLD = BM * BK / 4 / NTHREADS;   // float4 loads per thread per operand per K tile
-static constexpr int LD_K = 129;  // LDS row stride for transposed (K-contiguous) operands
-static constexpr int LD_R = 132;  // LDS row stride for row-contiguous operands
-static constexpr int LDS_OPERAND = BK * LD_R;  // floats per operand per buffer (max of the two)
+static constexpr int BM = 128, BK = SCTC_GEMM_BK, NTHREADS = 256;
+static constexpr int KQ = BK / 4;   // float4 per row of a K-contiguous operand tile
+// Block tile shapes.  128x128 (2x2 waves of 64x64) is the default; 128x96 (4x1 waves of
+// 32x96) serves column counts that 128 tiles badly: H = 1824 = 19 x 96 = 14.25 x 128.
+template <int BN_> struct TileCfg;
+template <> struct TileCfg<128> { static constexpr int WGM = 2, WGN = 2, OCC = SCTC_GEMM_OCC; };
+template <> struct TileCfg<96>  { static constexpr int WGM = 4, WGN = 1, OCC = 4; };
+// LDS row strides (floats): transposed (K-contiguous) operands get rows + 1 (conflict-free
+// scalar writes), row-contiguous operands rows + 4 (ds_write_b128)
+__host__ __device__ constexpr int lds_stride(bool kcontig, int rows) { return kcontig ? rows + 1 : rows + 4; }
+__host__ __device__ constexpr int lds_floats(int bn) { return 2 * BK * (BM + 4) + 2 * BK * (bn + 4); }
 
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& p, float v, int row, int col)
 {
@@ -46,19 +51,24 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& p, float v, int r
     return v;
 }
 
-template <bool AK, bool BKC>
-__global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmArgs p)
+template <bool AK, bool BKC, int BN_>
+__global__ __launch_bounds__(NTHREADS, TileCfg<BN_>::OCC) void gemm_f32_kernel(GemmArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int LDA = AK ? LD_K : LD_R;
-    constexpr int LDB = BKC ? LD_K : LD_R;
-    float* As = smem;                    // [2][BK][LDA]
-    float* Bs = smem + 2 * LDS_OPERAND;  // [2][BK][LDB]
+    constexpr int WGM = TileCfg<BN_>::WGM, WGN = TileCfg<BN_>::WGN;
+    constexpr int TM = BM / (WGM * 32), TN = BN_ / (WGN * 32);   // 32x32 MFMA tiles per wave
+    constexpr int LDA = lds_stride(AK, BM), LDB = lds_stride(BKC, BN_);
+    constexpr int OPA = BK * (BM + 4), OPB = BK * (BN_ + 4);     // floats per operand per buffer
+    constexpr int NA = BM * BK / 4, NB = BN_ * BK / 4;           // float4 per operand tile
+    constexpr int NLDA = (NA + NTHREADS - 1) / NTHREADS, NLDB = (NB + NTHREADS - 1) / NTHREADS;
+    constexpr int MQ = BM / 4, NQ = BN_ / 4;                     // float4 per row-contiguous k-row
+    float* As = smem;             // [2][BK][LDA]
+    float* Bs = smem + 2 * OPA;   // [2][BK][LDB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int M = p.M, N = p.N, K = p.K;
-    const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
+    const int mt = (M + BM - 1) / BM, nt = (N + BN_ - 1) / BN_;
     const int nblk = mt * nt;
     // XCD-aware, bijective remap (block b runs on XCD b % 8)
     int swz;
@@ -67,7 +77,7 @@ __global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmA
         swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
     const int tile_n = swz % nt, tile_m = swz / nt;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN_;
 
     // split-K range of this block
     const int ktiles = (K + BK - 1) / BK;
@@ -75,11 +85,11 @@ __global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmA
     const int kt_beg = blockIdx.y * per;
     const int kt_end = min(ktiles, kt_beg + per);
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -91,50 +101,56 @@ __global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmA
         // read some valid row and only feed accumulators the epilogue never stores; the K tail
         // is zeroed when the tile goes to LDS.  (A load behind a divergent branch costs an
         // exec-mask branch plus an early s_waitcnt, a select right behind the load a vmcnt(0).)
-        float4 ra[NLD], rb[NLD];
-        const float* pa[NLD];
-        const float* pb[NLD];
-        int ia[NLD], ib[NLD];   // row-contiguous operands: (gathered) row of the next tile
+        // Item f of a tile: K-contiguous -> row f / KQ, k = 4 (f % KQ);
+        //                   row-contiguous -> k-row f / (rows/4), column 4 (f % (rows/4)).
+        float4 ra[NLDA], rb[NLDB];
+        const float* pa[NLDA];
+        const float* pb[NLDB];
+        int ia[NLDA], ib[NLDB];   // row-contiguous operands: (gathered) row of the next tile
         const int Kc4 = (K - 1) & ~3, Kc1 = K - 1;
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int f = tid + NTHREADS * q;
+        for (int q = 0; q < NLDA; ++q) {
+            const int f = min(tid + NTHREADS * q, NA - 1);
             if constexpr (AK) {
                 pa[q] = p.A + (int64_t)min(m0 + f / KQ, M - 1) * p.lda;
             } else {
-                pa[q] = p.A + min(m0 + 4 * (f & 31), (M - 1) & ~3);
-                const int k = min(kt_beg * BK + (f >> 5), Kc1);
+                pa[q] = p.A + min(m0 + 4 * (f % MQ), (M - 1) & ~3);
+                const int k = min(kt_beg * BK + f / MQ, Kc1);
                 ia[q] = p.idx_a ? p.idx_a[k] : k;
             }
+        }
+#pragma unroll
+        for (int q = 0; q < NLDB; ++q) {
+            const int f = min(tid + NTHREADS * q, NB - 1);
             if constexpr (BKC) {
                 pb[q] = p.B + (int64_t)min(n0 + f / KQ, N - 1) * p.ldb;
             } else {
-                pb[q] = p.B + min(n0 + 4 * (f & 31), (N - 1) & ~3);
-                const int k = min(kt_beg * BK + (f >> 5), Kc1);
+                pb[q] = p.B + min(n0 + 4 * (f % NQ), (N - 1) & ~3);
+                const int k = min(kt_beg * BK + f / NQ, Kc1);
                 ib[q] = p.idx_b ? p.idx_b[k] : k;
             }
         }
         auto gload = [&](int kt) {
             const int k0 = kt * BK;
 #pragma unroll
-            for (int q = 0; q < NLD; ++q) {
-                const int f = tid + NTHREADS * q;
+            for (int q = 0; q < NLDA; ++q) {
+                const int f = min(tid + NTHREADS * q, NA - 1);
                 if constexpr (AK) {
                     ra[q] = *reinterpret_cast<const float4*>(pa[q] + min(k0 + 4 * (f % KQ), Kc4));
                 } else {
                     ra[q] = *reinterpret_cast<const float4*>(pa[q] + (uint32_t)ia[q] * (uint32_t)p.lda);
-                    const int kn = min(k0 + BK + (f >> 5), Kc1);
+                    const int kn = min(k0 + BK + f / MQ, Kc1);
                     ia[q] = p.idx_a ? p.idx_a[kn] : kn;
                 }
             }
 #pragma unroll
-            for (int q = 0; q < NLD; ++q) {
-                const int f = tid + NTHREADS * q;
+            for (int q = 0; q < NLDB; ++q) {
+                const int f = min(tid + NTHREADS * q, NB - 1);
                 if constexpr (BKC) {
                     rb[q] = *reinterpret_cast<const float4*>(pb[q] + min(k0 + 4 * (f % KQ), Kc4));
                 } else {
                     rb[q] = *reinterpret_cast<const float4*>(pb[q] + (uint32_t)ib[q] * (uint32_t)p.ldb);
-                    const int kn = min(k0 + BK + (f >> 5), Kc1);
+                    const int kn = min(k0 + BK + f / NQ, Kc1);
                     ib[q] = p.idx_b ? p.idx_b[kn] : kn;
                 }
             }
@@ -146,11 +162,12 @@ __global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmA
         // registers -> LDS tile `buf` of K tile kt; the A and B halves are separate so that they
         // can be slotted between different MFMA groups
         auto lstore_a = [&](int buf, int kt) {
-            float* a = As + buf * LDS_OPERAND;
+            float* a = As + buf * OPA;
             const bool tail = (kt + 1) * BK > K;   // uniform
 #pragma unroll
-            for (int q = 0; q < NLD; ++q) {
+            for (int q = 0; q < NLDA; ++q) {
                 const int f = tid + NTHREADS * q;
+                if (NA % NTHREADS != 0 && f >= NA) continue;
                 if constexpr (AK) {
                     const int r = f / KQ, kq = 4 * (f % KQ);
                     if (tail) zero_tail(ra[q], kt * BK + kq);
@@ -159,18 +176,19 @@ __global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmA
                     a[(kq + 2) * LDA + r] = ra[q].z;
                     a[(kq + 3) * LDA + r] = ra[q].w;
                 } else {
-                    const int kr = f >> 5, m = 4 * (f & 31);
+                    const int kr = f / MQ, m = 4 * (f % MQ);
                     if (tail) zero_tail(ra[q], kt * BK + kr);
                     *reinterpret_cast<float4*>(a + kr * LDA + m) = ra[q];
                 }
             }
         };
         auto lstore_b = [&](int buf, int kt) {
-            float* b = Bs + buf * LDS_OPERAND;
+            float* b = Bs + buf * OPB;
             const bool tail = (kt + 1) * BK > K;
 #pragma unroll
-            for (int q = 0; q < NLD; ++q) {
+            for (int q = 0; q < NLDB; ++q) {
                 const int f = tid + NTHREADS * q;
+                if (NB % NTHREADS != 0 && f >= NB) continue;   // 128x96: waves 2,3 hold no 2nd item
                 if constexpr (BKC) {
                     const int r = f / KQ, kq = 4 * (f % KQ);
                     if (tail) zero_tail(rb[q], kt * BK + kq);
@@ -179,7 +197,7 @@ __global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmA
                     b[(kq + 2) * LDB + r] = rb[q].z;
                     b[(kq + 3) * LDB + r] = rb[q].w;
                 } else {
-                    const int kr = f >> 5, n = 4 * (f & 31);
+                    const int kr = f / NQ, n = 4 * (f % NQ);
                     if (tail) zero_tail(rb[q], kt * BK + kr);
                     *reinterpret_cast<float4*>(b + kr * LDB + n) = rb[q];
                 }
@@ -201,30 +219,36 @@ __global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmA
             unsigned* st_out = reinterpret_cast<unsigned*>(p.splitk_ws) + (kt - kt_beg - 16) * 8;
             if (st_on) { st_out[0] = (unsigned)clock64(); st_out[5] = (unsigned)wall_clock64(); }
 #endif
-            const float* a = As + buf * LDS_OPERAND + kh * LDA + wm * 64 + li;
-            const float* b = Bs + buf * LDS_OPERAND + kh * LDB + wn * 64 + li;
-            // Software pipeline inside one K tile (NSTEP groups of 4 MFMAs = 256 matrix-pipe
+            const float* a = As + buf * OPA + kh * LDA + wm * (TM * 32) + li;
+            const float* b = Bs + buf * OPB + kh * LDB + wn * (TN * 32) + li;
+            // Software pipeline inside one K tile (NSTEP groups of TM x TN MFMAs, 64 matrix-pipe
             // cycles each).  Everything that is not an MFMA is slotted BEHIND a group so that it
-            // issues in that group's shadow: the LDS fragments of group s+1 behind group s-... ,
-            // the global loads of tile kt+1 behind group 0, its LDS stores behind the last
-            // groups (the data has had >= NSTEP-3 groups to arrive).
-            float a0 = a[0], a1 = a[32], b0 = b[0], b1 = b[32];
+            // issues in that group's shadow: the LDS fragments of group s+1, the global loads of
+            // tile kt+1 behind group 0, its LDS stores behind the last groups (the data has had
+            // >= NSTEP-3 groups to arrive).
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = a[32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = b[32 * j];
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
                 const int kk = 2 * s;
-                float a0n = 0.f, a1n = 0.f, b0n = 0.f, b1n = 0.f;
-                if (s + 1 < NSTEP) {
-                    a0n = a[(kk + 2) * LDA];
-                    a1n = a[(kk + 2) * LDA + 32];
-                    b0n = b[(kk + 2) * LDB];
-                    b1n = b[(kk + 2) * LDB + 32];
-                }
+                float an[TM], bn[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) an[i] = (s + 1 < NSTEP) ? a[(kk + 2) * LDA + 32 * i] : 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bn[j] = (s + 1 < NSTEP) ? b[(kk + 2) * LDB + 32 * j] : 0.f;
                 __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = an[i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = bn[j];
                 if (more) {
                     if (s == 0) { __builtin_amdgcn_sched_barrier(0); gload(kt + 1); }
                     if (s == NSTEP - 3) { __builtin_amdgcn_sched_barrier(0); lstore_a(buf ^ 1, kt + 1); }
@@ -253,11 +277,11 @@ __global__ __launch_bounds__(NTHREADS, SCTC_GEMM_OCC) void gemm_f32_kernel(GemmA
     const bool has_mask = !partial && p.mask, has_add = !partial && p.addend;
     const bool has_acc = !partial && p.accumulate;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            const int rbase = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
+            const int rbase = m0 + wm * (TM * 32) + i * 32 + 4 * (lane >> 5);
             const bool col_ok = col < N;
             const float bias = (!partial && p.bias && col_ok) ? p.bias[col] : 0.f;
             float mk[16], ad[16], cc[16];
@@ -299,15 +323,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p)
     }
 }
 
+// 96-column tiles when they waste at least 2 % fewer padded columns than 128-column tiles
+int gemm_pick_bn(int N)
+{
+    const double w128 = (double)((N + 127) / 128 * 128) / N, w96 = (double)((N + 95) / 96 * 96) / N;
+    return w96 + 0.02 < w128 ? 96 : 128;
+}
+
 int64_t gemm_plan_splits(int M, int N, int K, int* splits)
 {
-    const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
+    const int bn = gemm_pick_bn(N);
+    const int occ = bn == 96 ? TileCfg<96>::OCC : TileCfg<128>::OCC;
+    const int mt = (M + BM - 1) / BM, nt = (N + bn - 1) / bn;
     const int ktiles = (K + BK - 1) / BK;
     int s = 1;
-    // 256 CUs x 2 resident blocks = 512 slots.  A grid that is not a multiple of that leaves a
-    // partial last round (225 tiles x 3 splits = 675 blocks ran at 66 %); pick the split that
-    // fills whole rounds best, keeping >= 8 K tiles per split.
-    const int tiles = mt * nt, slots = 256 * SCTC_GEMM_OCC;
+    // 256 CUs x `occ` resident blocks.  A grid that is not a multiple of that leaves a partial
+    // last round (225 tiles x 3 splits = 675 blocks ran at 66 %); pick the split that fills
+    // whole rounds best, keeping >= 8 K tiles per split.
+    const int tiles = mt * nt, slots = 256 * occ;
     if (tiles < 2 * slots) {
         double best = 0.0;
         const int smax = std::min(64, std::max(1, ktiles / 8));
@@ -323,6 +356,29 @@ int64_t gemm_plan_splits(int M, int N, int K, int* splits)
     return s > 1 ? (int64_t)s * M * N : 0;
 }
 
+template <int BN_>
+static int launch_tiles(GemmArgs a, hipStream_t stream)
+{
+    const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN_ - 1) / BN_;
+    dim3 grid(mt * nt, a.splits), block(NTHREADS);
+    const size_t smem = sizeof(float) * lds_floats(BN_);  // 2 operands x 2 buffers
+    void (*kern)(GemmArgs) = nullptr;
+    if (a.a_kcontig && a.b_kcontig) kern = gemm_f32_kernel<true, true, BN_>;
+    else if (a.a_kcontig && !a.b_kcontig) kern = gemm_f32_kernel<true, false, BN_>;
+    else if (!a.a_kcontig && a.b_kcontig) kern = gemm_f32_kernel<false, true, BN_>;
+    else kern = gemm_f32_kernel<false, false, BN_>;
+    static bool attr_set[4] = {false, false, false, false};
+    const int vi = (a.a_kcontig ? 2 : 0) + (a.b_kcontig ? 1 : 0);
+    if (!attr_set[vi]) {
+        SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set[vi] = true;
+    }
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, a);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
 int launch_gemm_f32(GemmArgs a, hipStream_t stream)
 {
     if (a.M <= 0 || a.N <= 0) return SCTC_OK;
@@ -336,23 +392,9 @@ int launch_gemm_f32(GemmArgs a, hipStream_t stream)
     else SCTC_CHECK_ARG(a.N % 4 == 0, "gemm: N must be a multiple of 4 (B row-contig)");
     if (a.splits < 1) a.splits = 1;
     if (a.splits > 1) SCTC_CHECK_ARG(a.splitk_ws != nullptr, "gemm: split-K without workspace");
-    const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
-    dim3 grid(mt * nt, a.splits), block(NTHREADS);
-    const size_t smem = sizeof(float) * 4 * LDS_OPERAND;  // 2 operands x 2 buffers
-    void (*kern)(GemmArgs) = nullptr;
-    if (a.a_kcontig && a.b_kcontig) kern = gemm_f32_kernel<true, true>;
-    else if (a.a_kcontig && !a.b_kcontig) kern = gemm_f32_kernel<true, false>;
-    else if (!a.a_kcontig && a.b_kcontig) kern = gemm_f32_kernel<false, true>;
-    else kern = gemm_f32_kernel<false, false>;
-    static bool attr_set[4] = {false, false, false, false};
-    const int vi = (a.a_kcontig ? 2 : 0) + (a.b_kcontig ? 1 : 0);
-    if (!attr_set[vi]) {
-        SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set[vi] = true;
-    }
-    hipLaunchKernelGGL(kern, grid, block, smem, stream, a);
-    SCTC_HIP_TRY(hipGetLastError());
+    const char* force = getenv("SCTC_GEMM_BN");   // diagnostics: 96 / 128
+    const int bn = force ? atoi(force) : gemm_pick_bn(a.N);
+    SCTC_TRY(bn == 96 ? launch_tiles<96>(a, stream) : launch_tiles<128>(a, stream));
     if (a.splits > 1) {
         const int64_t total = (int64_t)a.M * a.N;
         int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
