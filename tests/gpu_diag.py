@@ -128,6 +128,65 @@ def sec_gemmk():
             del a, b, c
 
 
+def sec_twostream():
+    """experiment: two half-minibatches (2 x 16 utterances) on two streams/threads vs one
+    minibatch of 32 -- does GEMM work of one half fill the matrix pipes while the other half
+    sits in its latency-bound recurrence?"""
+    import threading
+    from nnets import brnnet
+    D, A, H, NL, TL, T, U = 483, 33, 1824, 5, 3, 1000, 100
+    rs = np.random.RandomState(1)
+
+    def make(B):
+        np.random.seed(0)
+        net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B)
+        net.initParams()
+        feats = torch.randn(B * T, D, device="cuda")
+        labels = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
+        return net, feats, labels, [T] * B
+
+    steps = 6
+    one = make(32)
+    for _ in range(2):
+        one[0].costAndGradBatch(None, one[2], feats_dev=one[1], T_b=one[3])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one[0].costAndGradBatch(None, one[2], feats_dev=one[1], T_b=one[3])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter() - t0
+    print("one stream  B=32: %.2f ms/step  %.0f frames/s" % (t1 / steps * 1e3, 32 * T * steps / t1))
+    del one
+    halves = [make(16), make(16)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def worker(i, n):
+        net, feats, labels, Ts = halves[i]
+        with torch.cuda.stream(streams[i]):
+            for _ in range(n):
+                net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+            streams[i].synchronize()
+
+    for n in (2, steps):
+        th = [threading.Thread(target=worker, args=(i, n)) for i in range(2)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter() - t0
+    print("two streams 2xB=16: %.2f ms per pair of half-steps  %.0f frames/s" %
+          (t2 / steps * 1e3, 32 * T * steps / t2))
+    # one half alone, for reference
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    worker(0, steps)
+    t3 = time.perf_counter() - t0
+    print("one stream  B=16: %.2f ms/step  %.0f frames/s" % (t3 / steps * 1e3, 16 * T * steps / t3))
+
+
 def sec_gemmstamp():
     """per-K-tile timeline of one GEMM block (needs a library built with -DSCTC_GEMM_STAMP)"""
     L = _sctc.lib()
@@ -157,6 +216,7 @@ def sec_ctc():
     import ctc_fast
     rs = np.random.RandomState(0)
     for (B, T, U, A) in ((32, 1000, 100, 33), (1, 1000, 100, 33), (256, 1000, 100, 33),
+                         (1024, 1000, 100, 33), (4096, 1000, 100, 33),
                          (32, 2000, 200, 33), (8, 8000, 800, 33)):
         logits = torch.randn(B * T, A, device="cuda")
         probs = torch.softmax(logits, dim=1).contiguous()
@@ -240,7 +300,7 @@ def sec_recdbg(sync=0):
 
 def main():
     want = sys.argv[1:] or ["info", "gemm", "ctc", "brnn"]
-    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "gemmstamp": sec_gemmstamp, "gemmk": sec_gemmk, "ctc": sec_ctc,
+    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "gemmstamp": sec_gemmstamp, "gemmk": sec_gemmk, "twostream": sec_twostream, "ctc": sec_ctc,
              "brnn": lambda: sec_brnn("cfg3", 32, 0),
              "brnn1": lambda: sec_brnn("cfg3", 32, 1),
              "recdbg": lambda: sec_recdbg(0), "recdbg1": lambda: sec_recdbg(1),
