@@ -210,7 +210,7 @@ def main():
                 out["roofline_ctc"]["traffic"] = sum(
                     c[k]["fetch_bytes"] + c[k]["write_bytes"]
                     for k in ("softmax_rows_kernel", "ctc_lattice_kernel", "ctc_grad_kernel"))
-        if not args.no_side:
+        if world == 1 and not args.no_side:
             side_measurements(out, net, feats, labels, Ts, rs, torch, B, T, D)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)

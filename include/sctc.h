@@ -52,6 +52,12 @@ int sctc_device_info(int* compute_units, int* lds_bytes_per_cu, int64_t* total_m
                      char* name, int name_len);
 /* runs the cross-lane / MFMA fragment-layout probes; 0 = all as expected, else a bitmask */
 int sctc_selftest(void* stream);
+/* diagnostics: hand-off latencies between workgroups on the same / on different XCDs (flag
+ * ping-pong per polling-load scope, 1 KiB tagged payload); the one entry point that allocates
+ * (and frees) its own scratch.  results_host[10]: partner block ids (same, cross XCD), then
+ * microseconds per round trip: same-XCD {sc0, sc1, sc0+sc1}, cross-XCD {sc0, sc1, sc0+sc1},
+ * tagged payload {same, cross}; -1 = timed out (e.g. a scope that never observes the store) */
+int sctc_probe_fabric(float* results_host, int32_t n_results, void* stream);
 
 /* ---- CTC: ctc_fast/ctc-loss/ctc_fast.pyx ------------------------------- */
 

@@ -36,11 +36,20 @@ struct RecArgs {
     unsigned* counters;     // [REC_COUNTER_WORDS]: error word at [2], per-producer step flags from [4]
     int32_t sync_mode;      // 0: plain exchange stores + agent-scope release fence before the flag
                             // 1: write-through (sc1) exchange stores, no fence
-    int32_t variant;        // 0: pick automatically; 1: force the one-workgroup-per-CU kernel
+    int32_t variant;        // 0: pick automatically; 1: force the one-workgroup-per-CU kernel;
+                            // 2: two-chain kernel with the linear (not XCD-grouped) block map
     unsigned* debug;        // nullable: s_memtime stamps [2 wgs][16 steps][8] for steps 64..79
 };
-static constexpr int REC_DEBUG_WORDS = 2 * 16 * 8;
-static constexpr int REC_COUNTER_WORDS = 4 + 4 * 128;   // error word + up to 4 chains x 128 producers
+// [2 wgs][16 steps][8] s_memtime stamps of steps 64..79, then [512 workgroups][8] wall-clock
+// (100 MHz, global) stamps of step 70 for every workgroup
+static constexpr int REC_DEBUG_ALL_OFF = 2 * 16 * 8;
+static constexpr int REC_DEBUG_WORDS = 2 * 16 * 8 + 512 * 8;
+#ifndef SCTC_REC_FLAG_STRIDE
+#define SCTC_REC_FLAG_STRIDE 8
+#endif
+// words between the step flags of two producers (32 = one 128-byte line per flag)
+static constexpr int REC_FLAG_STRIDE = SCTC_REC_FLAG_STRIDE;
+static constexpr int REC_COUNTER_WORDS = 32 + 4 * 128 * REC_FLAG_STRIDE;   // error word + up to 4 chains x 128 producers
 
 // exchange rows needed for `rows` frames spread over `tmax` time steps (worst case)
 static inline int64_t recurrent_xrows_bound(int64_t rows, int64_t tmax) { return rows + 3 * tmax; }

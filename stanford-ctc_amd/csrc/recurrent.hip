@@ -85,9 +85,9 @@ __device__ __forceinline__ void wait_all(unsigned* flags, int nwg, unsigned targ
         for (;;) {
             unsigned f0 = target, f1 = target;
             if (lane < nwg)
-                f0 = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                f0 = __hip_atomic_load(flags + lane * REC_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane + 64 < nwg)
-                f1 = __hip_atomic_load(flags + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                f1 = __hip_atomic_load(flags + (lane + 64) * REC_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all(f0 >= target && f1 >= target)) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 255u) == 0) {
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
     float* out = p.out[g];
     const int64_t ld = p.ld;
     const float hi = p.max_act > 0.f ? p.max_act : INFINITY;
-    unsigned* flags = p.counters + 4 + g * 128;  // [2][128] step flags
+    unsigned* flags = p.counters + 32 + g * 128 * REC_FLAG_STRIDE;  // [2][128] step flags
     unsigned* err = p.counters + 2;
     const unsigned chunk_stride = (unsigned)p.n_xrows * 64u;  // bytes per 16-unit chunk
     float* xg = p.xbuf + (size_t)g * p.n_xrows * Hp;
@@ -175,6 +175,10 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
     auto stamp = [&](int j, int k) {
         if (dbg_sel >= 0 && j >= 64 && j < 80)
             p.debug[(dbg_sel * 16 + (j - 64)) * 8 + k] = (unsigned)clock64();
+        if (p.debug && tid == 0 && j == 70) {   // every workgroup: global 100 MHz clock, chain tag
+            p.debug[REC_DEBUG_ALL_OFF + blockIdx.x * 8 + k] = (unsigned)wall_clock64();
+            if (k == 0) p.debug[REC_DEBUG_ALL_OFF + blockIdx.x * 8 + 7] = 1u + (unsigned)g;
+        }
     };
 
     for (int j = 0; j < p.Tmax; ++j) {
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
             }
         }
         stamp(j, 4);
-        if (j + 1 < p.Tmax) publish_step(flags + wg, (unsigned)(j + 1), sync_mode);
+        if (j + 1 < p.Tmax) publish_step(flags + wg * REC_FLAG_STRIDE, (unsigned)(j + 1), sync_mode);
         stamp(j, 5);
     }
 }
@@ -327,7 +331,8 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
 // quarters (the 114 chunks of H = 1824 split 29/29/28/28); the 16 x H weight slab no longer
 // fits twice into 160 KiB of LDS, so each wave keeps NREG of its chunks in registers and the
 // rest in a wave-private LDS region.  Exchange traffic per CU and step is unchanged (2 x 16
-// utterances), flags are per chain: counters[4 + chain*128 + wg].
+// utterances), flags are per chain: counters[32 + (chain*128 + wg) * REC_FLAG_STRIDE] (own 32-byte
+// slots: 114 writers and 456 pollers on four shared cache lines cost 8 % of the step).
 template <int NCQ, int NREG>
 __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
 {
@@ -336,7 +341,31 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Hp = p.Hp, nch = Hp >> 4, nwg = nch;
-    const int chain = blockIdx.x / nwg, wg = blockIdx.x - chain * nwg;
+    // Block -> (chain, producer) map.  Workgroups are dealt to XCDs round-robin (block b runs on
+    // XCD b % 8, probed by sctc_probe_fabric); the XCD-grouped map confines utterance tile 0 to
+    // XCDs 0-3 and tile 1 to XCDs 4-7 (both directions each), so an XCD's L2 fetches the state
+    // of two chains instead of four and a quarter of a chain's producers are L2-local; the two
+    // workgroups that land on one CU (k and k+32 of an XCD) still belong to different chains.
+    // Placement only affects speed: any block -> XCD assignment gives the same results.
+    int chain, wg;
+    if (p.variant != 2) {
+        const int x = blockIdx.x & 7, k = blockIdx.x >> 3, P = nwg >> 1;   // P blocks per XCD
+        const int gx = x >> 2, xl = x & 3;
+        const int n0_even = (P + 1) >> 1, n0_odd = P >> 1;                  // chain-0 share per XCD
+        const int n0 = (xl & 1) ? n0_odd : n0_even;
+        const int cl = k < n0 ? 0 : 1;
+        const int i = cl == 0 ? k : k - n0;
+        int before = 0;   // producers of this chain on the XCDs before this one
+        for (int q = 0; q < xl; ++q) {
+            const int m0 = (q & 1) ? n0_odd : n0_even;
+            before += cl == 0 ? m0 : P - m0;
+        }
+        chain = 2 * gx + cl;
+        wg = before + i;
+    } else {
+        chain = blockIdx.x / nwg;
+        wg = blockIdx.x - chain * nwg;
+    }
     const int g = chain & 1, tile = chain >> 1;
     const int row0 = wg * 16;
     const int uj = lane & 15, kq = lane >> 4;
@@ -376,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
     float* out = p.out[g];
     const int64_t ld = p.ld;
     const float hi = p.max_act > 0.f ? p.max_act : INFINITY;
-    unsigned* flags = p.counters + 4 + chain * 128;
+    unsigned* flags = p.counters + 32 + chain * 128 * REC_FLAG_STRIDE;
     unsigned* err = p.counters + 2;
     const unsigned chunk_stride = (unsigned)p.n_xrows * 64u;
     float* xg = p.xbuf + (size_t)g * p.n_xrows * Hp;
@@ -392,6 +421,10 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
     auto stamp = [&](int j, int k) {
         if (dbg_sel >= 0 && j >= 64 && j < 80)
             p.debug[(dbg_sel * 16 + (j - 64)) * 8 + k] = (unsigned)clock64();
+        if (p.debug && tid == 0 && j == 70) {   // every workgroup: global 100 MHz clock, chain tag
+            p.debug[REC_DEBUG_ALL_OFF + blockIdx.x * 8 + k] = (unsigned)wall_clock64();
+            if (k == 0) p.debug[REC_DEBUG_ALL_OFF + blockIdx.x * 8 + 7] = 1u + (unsigned)chain;
+        }
     };
 
     // rowbase / xbase of a step are fetched one step ahead: three dependent L2 round trips at
@@ -475,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
             st_x(xrsrc, xout, (unsigned)wg * chunk_stride, o, sync_mode);
         }
         stamp(j, 4);
-        if (j + 1 < Tchain) publish_step(flags + wg, (unsigned)(j + 1), sync_mode);
+        if (j + 1 < Tchain) publish_step(flags + wg * REC_FLAG_STRIDE, (unsigned)(j + 1), sync_mode);
         stamp(j, 5);
     }
 }
@@ -527,7 +560,7 @@ int launch_recurrent(const RecArgs& a, hipStream_t stream)
                          "has %d CUs", 2 * nwg, cus);
     const int ntiles = (a.B + 15) / 16;
     SCTC_HIP_TRY(hipMemsetAsync(a.counters, 0, REC_COUNTER_WORDS * sizeof(unsigned), stream));
-    if (ntiles == 2 && a.variant != 1 && 4 * nwg <= 2 * cus) {
+    if (ntiles == 2 && a.variant != 1 && 4 * nwg <= 2 * cus && (4 * nwg) % 8 == 0) {
         // two chains per CU; NREG keeps the LDS share of the slab at <= 76 KiB per workgroup
         RecKernel qk = nullptr;
         int ncq = 0, nreg = 0;

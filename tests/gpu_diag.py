@@ -187,6 +187,20 @@ def sec_twostream():
     print("one stream  B=16: %.2f ms/step  %.0f frames/s" % (t3 / steps * 1e3, 16 * T * steps / t3))
 
 
+def sec_fabric():
+    """hand-off latencies between workgroups (same XCD / different XCDs)"""
+    L = _sctc.lib()
+    for rep in range(2):
+        out = (ctypes.c_float * 10)()
+        rc = L.sctc_probe_fabric(out, 10, None)
+        assert rc == 0, L.sctc_last_error()
+        v = list(out)
+        print("partners: same-XCD block %d, cross-XCD block %d" % (v[0], v[1]))
+        print("  flag ping-pong us/round trip  same XCD: sc0 %.2f  sc1 %.2f  sc0+sc1 %.2f" % tuple(v[2:5]))
+        print("  flag ping-pong us/round trip cross XCD: sc0 %.2f  sc1 %.2f  sc0+sc1 %.2f" % tuple(v[5:8]))
+        print("  tagged 1 KiB payload us/round trip: same %.2f  cross %.2f" % tuple(v[8:10]))
+
+
 def sec_gemmstamp():
     """per-K-tile timeline of one GEMM block (needs a library built with -DSCTC_GEMM_STAMP)"""
     L = _sctc.lib()
@@ -284,9 +298,24 @@ def sec_recdbg(sync=0):
     labels = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
     for _ in range(2):
         net.costAndGradBatch(None, labels, feats_dev=feats, T_b=[T] * B)
-    buf = np.zeros(2 * 2 * 16 * 8, dtype=np.uint32)
+    W = 2 * 16 * 8 + 512 * 8
+    buf = np.zeros(2 * W, dtype=np.uint32)
     _sctc.lib().sctc_brnn_debug_read(net._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size)
-    st = buf.reshape(2, 2, 16, 8).astype(np.int64)
+    both = buf.reshape(2, W).astype(np.int64)
+    st = both[:, :256].reshape(2, 2, 16, 8)
+    # every workgroup's wall-clock (10 ns) stamps of step 70: who publishes when, who sees it when
+    for ps, pname in enumerate(("forward", "bptt")):
+        a = both[ps, 256:].reshape(512, 8)
+        a = a[a[:, 7] != 0]
+        for c in sorted(set(a[:, 7])):
+            w = a[a[:, 7] == c]
+            c = c - 1
+            t0 = w[:, 0].min()
+            rel = (w[:, :6] - t0) * 0.01
+            names6 = ["step start", "flags seen", "mfma done", "reduced", "stored", "published"]
+            print("%s chain %d (%d wgs), us after first wg started step 70:" % (pname, c, len(w)))
+            for k in range(6):
+                print("    %-11s min %.2f  median %.2f  max %.2f" % (names6[k], rel[:, k].min(), np.median(rel[:, k]), rel[:, k].max()))
     names = ["wait", "load+mfma", "lds-reduce", "epilogue", "publish"]
     for ps, pname in enumerate(("forward", "bptt")):
         for w in range(2):
@@ -300,7 +329,7 @@ def sec_recdbg(sync=0):
 
 def main():
     want = sys.argv[1:] or ["info", "gemm", "ctc", "brnn"]
-    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "gemmstamp": sec_gemmstamp, "gemmk": sec_gemmk, "twostream": sec_twostream, "ctc": sec_ctc,
+    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "gemmstamp": sec_gemmstamp, "gemmk": sec_gemmk, "twostream": sec_twostream, "fabric": sec_fabric, "ctc": sec_ctc,
              "brnn": lambda: sec_brnn("cfg3", 32, 0),
              "brnn1": lambda: sec_brnn("cfg3", 32, 1),
              "recdbg": lambda: sec_recdbg(0), "recdbg1": lambda: sec_recdbg(1),
