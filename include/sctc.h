@@ -58,6 +58,10 @@ int sctc_selftest(void* stream);
  * microseconds per round trip: same-XCD {sc0, sc1, sc0+sc1}, cross-XCD {sc0, sc1, sc0+sc1},
  * tagged payload {same, cross}; -1 = timed out (e.g. a scope that never observes the store) */
 int sctc_probe_fabric(float* results_host, int32_t n_results, void* stream);
+/* diagnostics: sustained fp32 matrix-pipe rate of register-only MFMA loops on every SIMD:
+ * results_host[8] = {TFLOP/s, ms} for v_mfma_f32_32x32x2_f32 and v_mfma_f32_16x16x4_f32 with
+ * constant operands, then the same two with fresh random operands per MFMA group */
+int sctc_probe_mfma(float* results_host, int32_t n_results, void* stream);
 
 /* ---- CTC: ctc_fast/ctc-loss/ctc_fast.pyx ------------------------------- */
 

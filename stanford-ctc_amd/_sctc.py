@@ -57,6 +57,7 @@ PROTOTYPES = {
     "sctc_device_info": (ctypes.c_int, [c_i32p, c_i32p, c_i64p, ctypes.c_char_p, ctypes.c_int]),
     "sctc_selftest": (ctypes.c_int, [vp]),
     "sctc_probe_fabric": (ctypes.c_int, [c_f32p, ctypes.c_int32, vp]),
+    "sctc_probe_mfma": (ctypes.c_int, [c_f32p, ctypes.c_int32, vp]),
     "sctc_ctc_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(CtcBatch)]),
     "sctc_ctc_loss_batch": (ctypes.c_int, [ctypes.POINTER(CtcBatch), vp, vp, vp, vp, vp,
                                            ctypes.c_size_t, vp]),

@@ -177,3 +177,98 @@ extern "C" int sctc_probe_fabric(float* results_host, int32_t n_results, void* s
     if (e != hipSuccess) return set_error(SCTC_ERR_HIP, "probe_fabric: %s", hipGetErrorString(e));
     return SCTC_OK;
 }
+
+// ---- sustained matrix-pipe rate: register-only MFMA loops (no memory traffic), every SIMD of
+// every CU busy.  The fp32 MFMA peak of 157.3 TFLOP/s assumes 2.4 GHz; this measures what the
+// part sustains under that load (power management lowers the shader clock).
+namespace sctc {
+
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+typedef float pf32x16 __attribute__((ext_vector_type(16)));
+
+template <int SHAPE, bool RANDOM>
+__global__ __launch_bounds__(256) void mfma_rate_kernel(float* sink, int iters)
+{
+    float a = 1.0f + threadIdx.x * 1e-6f, b = 1.0f - threadIdx.x * 1e-6f;
+    unsigned rng = 0x9e3779b9u * (threadIdx.x + 1 + blockIdx.x * 256);
+    if (SHAPE == 32) {
+        pf32x16 acc[4];
+        for (int i = 0; i < 4; ++i)
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (RANDOM) {   // fresh random mantissas: realistic toggling in the multiplier arrays
+                    rng = rng * 1664525u + 1013904223u;
+                    a = __uint_as_float(0x3f000000u | (rng >> 9));
+                    b = __uint_as_float(0x3f000000u | ((rng * 2654435761u) >> 9));
+                }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[3], 0, 0, 0);
+            }
+        }
+        float s = 0.f;
+        for (int i = 0; i < 4; ++i) s += acc[i][0];
+        if (s == 123.456f) sink[0] = s;
+    } else {
+        pf32x4 acc[8];
+        for (int i = 0; i < 8; ++i)
+            for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (RANDOM) {
+                    rng = rng * 1664525u + 1013904223u;
+                    a = __uint_as_float(0x3f000000u | (rng >> 9));
+                    b = __uint_as_float(0x3f000000u | ((rng * 2654435761u) >> 9));
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+            }
+        }
+        float s = 0.f;
+        for (int i = 0; i < 8; ++i) s += acc[i][0];
+        if (s == 123.456f) sink[0] = s;
+    }
+}
+
+}  // namespace sctc
+
+extern "C" int sctc_probe_mfma(float* results_host, int32_t n_results, void* stream)
+{
+    using namespace sctc;
+    SCTC_CHECK_ARG(results_host && n_results >= 8, "probe_mfma: need room for 8 floats");
+    hipStream_t s = (hipStream_t)stream;
+    float* sink = nullptr;
+    SCTC_HIP_TRY(hipMalloc(&sink, 64));
+    hipEvent_t e0, e1;
+    SCTC_HIP_TRY(hipEventCreate(&e0));
+    SCTC_HIP_TRY(hipEventCreate(&e1));
+    const int blocks = 256 * 3, iters = 4000;   // 3 blocks x 4 waves per CU = 3 waves per SIMD
+    for (int shape = 0; shape < 4; ++shape) {   // 0,1: constant operands; 2,3: random operands
+        for (int rep = 0; rep < 2; ++rep) {     // rep 0 warms up / lets the clock settle
+            hipEventRecord(e0, s);
+            if (shape == 0) hipLaunchKernelGGL((mfma_rate_kernel<32, false>), dim3(blocks), dim3(256), 0, s, sink, iters);
+            else if (shape == 1) hipLaunchKernelGGL((mfma_rate_kernel<16, false>), dim3(blocks), dim3(256), 0, s, sink, iters);
+            else if (shape == 2) hipLaunchKernelGGL((mfma_rate_kernel<32, true>), dim3(blocks), dim3(256), 0, s, sink, iters);
+            else hipLaunchKernelGGL((mfma_rate_kernel<16, true>), dim3(blocks), dim3(256), 0, s, sink, iters);
+            hipEventRecord(e1, s);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            // flops: blocks * 4 waves * iters * 32 MFMAs * (2*32*32*2) [32x32x2]  or 64 MFMAs * (2*16*16*4)
+            const double fl = (double)blocks * 4 * iters * ((shape & 1) == 0 ? 32.0 * 4096.0 : 64.0 * 2048.0);
+            results_host[shape * 2 + 0] = (float)(fl / (ms * 1e-3) / 1e12);
+            results_host[shape * 2 + 1] = ms;
+        }
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(sink);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(SCTC_ERR_HIP, "probe_mfma: %s", hipGetErrorString(e));
+    return SCTC_OK;
+}

@@ -201,6 +201,17 @@ def sec_fabric():
         print("  tagged 1 KiB payload us/round trip: same %.2f  cross %.2f" % tuple(v[8:10]))
 
 
+def sec_mfmarate():
+    """sustained fp32 MFMA rate without memory traffic (what the clock under load allows)"""
+    L = _sctc.lib()
+    out = (ctypes.c_float * 8)()
+    assert L.sctc_probe_mfma(out, 8, None) == 0, L.sctc_last_error()
+    print("pure MFMA loops, 3 waves/SIMD on all CUs, constant operands: 32x32x2 f32 %.1f TFLOP/s (%.2f ms), "
+          "16x16x4 f32 %.1f TFLOP/s (%.2f ms); nominal peak 157.3 at 2.4 GHz" % tuple(out[:4]))
+    print("   random operands per MFMA group:                         32x32x2 f32 %.1f TFLOP/s (%.2f ms), "
+          "16x16x4 f32 %.1f TFLOP/s (%.2f ms)" % tuple(out[4:]))
+
+
 def sec_gemmstamp():
     """per-K-tile timeline of one GEMM block (needs a library built with -DSCTC_GEMM_STAMP)"""
     L = _sctc.lib()
@@ -329,7 +340,7 @@ def sec_recdbg(sync=0):
 
 def main():
     want = sys.argv[1:] or ["info", "gemm", "ctc", "brnn"]
-    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "gemmstamp": sec_gemmstamp, "gemmk": sec_gemmk, "twostream": sec_twostream, "fabric": sec_fabric, "ctc": sec_ctc,
+    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "gemmstamp": sec_gemmstamp, "gemmk": sec_gemmk, "twostream": sec_twostream, "fabric": sec_fabric, "mfmarate": sec_mfmarate, "ctc": sec_ctc,
              "brnn": lambda: sec_brnn("cfg3", 32, 0),
              "brnn1": lambda: sec_brnn("cfg3", 32, 1),
              "recdbg": lambda: sec_recdbg(0), "recdbg1": lambda: sec_recdbg(1),
