@@ -56,7 +56,6 @@ struct sctc_brnn {
     size_t ctc_ws_bytes;
     float* splitk_ws;
     int64_t splitk_floats;
-    float* colsum_ws;
     float* xbuf;
     unsigned* counters;
     unsigned* rec_debug = nullptr;  // [2 passes][REC_DEBUG_WORDS] step timestamps (SCTC_REC_DEBUG=1)
@@ -206,7 +205,6 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
         }
     }
     float* splitk_ws = sk ? f(sk) : nullptr;
-    float* colsum_ws = c->train ? f(colsum_ws_floats(F, std::max(d.Hp, d.Ap))) : nullptr;
     float* xbuf = d.TL > 0 ? f((int64_t)recurrent_xbuf_floats(d.Hp, recurrent_xrows_bound(F, F))) : nullptr;
     unsigned* counters = ar.take<unsigned>(REC_COUNTER_WORDS);
     unsigned* rec_debug = ar.take<unsigned>(2 * REC_DEBUG_WORDS);
@@ -223,7 +221,7 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
         h->d_rowbase = d_rowbase; h->d_nact = d_nact; h->d_Ts = d_Ts; h->d_src_row = d_src_row;
         h->d_idx_lo = d_idx_lo; h->d_idx_hi = d_idx_hi; h->d_perm = d_perm; h->d_xbase = d_xbase;
         h->ctc_ws = ctc_ws; h->ctc_ws_bytes = ctc_bytes;
-        h->splitk_ws = splitk_ws; h->splitk_floats = sk; h->colsum_ws = colsum_ws;
+        h->splitk_ws = splitk_ws; h->splitk_floats = sk;
         h->xbuf = xbuf; h->counters = counters; h->rec_debug = rec_debug;
         h->d_cost = d_cost; h->d_skip = d_skip; h->d_cost_out = d_cost_out;
         h->d_skip_out = d_skip_out; h->d_sumsq = d_sumsq; h->sumsq_ws = sumsq_ws;
@@ -517,16 +515,14 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             g.ldc = LD(inp);
             g.accumulate = acc;
             if (reg > 0.f) { g.addend = W; g.ldadd = LD(inp); g.add_scale = reg; }
+            // db = deltasIn.sum(axis=1), brnnet.py:200: column sums of the A operand, fused
+            g.colsum_a = h->grads + h->tinfo[bias_index(h, i)].offset;
             g.splitk_ws = h->splitk_ws;
             int splits = 1;
             gemm_plan_splits(g.M, g.N, g.K, &splits);
             g.splits = splits;
             SCTC_TRY(launch_gemm_f32(g, s));
         }
-        // db = deltasIn.sum(axis=1), brnnet.py:200
-        pt.begin(SCTC_PHASE_OTHER);
-        SCTC_TRY(launch_colsum(d_in, d_in_ld, N, outp,
-                               h->grads + h->tinfo[bias_index(h, i)].offset, acc, h->colsum_ws, s));
         if (i == 0) break;
         pt.begin(SCTC_PHASE_BWD_GEMM);
         // deltasOut = W^T deltasIn, brnnet.py:204  (+ sign(hActs[i]) mask, :235-237)

@@ -9,9 +9,6 @@ int launch_gather_rows(float* dst, int64_t ldd, const float* src, int64_t lds, c
 int launch_scatter_rows(float* dst, int64_t ldd, const float* src, int64_t lds,
                         const int32_t* idx, int64_t rows, int cols, hipStream_t s);
 int launch_add(float* out, const float* a, const float* b, int64_t n, hipStream_t s);
-int64_t colsum_ws_floats(int64_t rows, int cols);
-int launch_colsum(const float* x, int64_t ld, int64_t rows, int cols, float* out, int accumulate,
-                  float* ws, hipStream_t s);
 size_t sumsq_ws_bytes();
 int launch_sumsq(const float* x, int64_t n, double* out, double* ws, hipStream_t s);
 

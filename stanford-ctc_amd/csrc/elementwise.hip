@@ -45,33 +45,6 @@ __global__ __launch_bounds__(256) void add_kernel(float4* __restrict__ out,
     }
 }
 
-// stage 1 of the bias gradient (brnnet.py:200 deltasIn.sum(axis=1)):
-// partial[chunk][c] = sum over the chunk's rows of x[r][c]; fixed order => reproducible
-static constexpr int CS_ROWS = 256;
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x,
-                                                             int64_t ld, int64_t rows, int cols,
-                                                             float* __restrict__ partial)
-{
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
-    const int64_t r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
-    if (c >= cols) return;
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += x[r * ld + c];
-    partial[(int64_t)blockIdx.y * cols + c] = s;
-}
-
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial,
-                                                           int nchunks, int cols,
-                                                           float* __restrict__ out, int accumulate)
-{
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    float s = 0.f;
-    for (int k = 0; k < nchunks; ++k) s += partial[(int64_t)k * cols + c];
-    out[c] = accumulate ? out[c] + s : s;
-}
-
 __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y,
                                                    const float* __restrict__ x, float alpha,
                                                    int64_t n)
@@ -173,26 +146,6 @@ int launch_add(float* out, const float* a, const float* b, int64_t n, hipStream_
     SCTC_CHECK_ARG(n % 4 == 0, "add: element count must be a multiple of 4");
     hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, (float4*)out,
                        (const float4*)a, (const float4*)b, n / 4);
-    SCTC_HIP_TRY(hipGetLastError());
-    return SCTC_OK;
-}
-
-int64_t colsum_ws_floats(int64_t rows, int cols)
-{
-    return ((rows + CS_ROWS - 1) / CS_ROWS) * (int64_t)cols;
-}
-
-int launch_colsum(const float* x, int64_t ld, int64_t rows, int cols, float* out, int accumulate,
-                  float* ws, hipStream_t s)
-{
-    if (cols <= 0) return SCTC_OK;
-    const int nchunks = (int)((rows + CS_ROWS - 1) / CS_ROWS);
-    const int cb = (cols + 255) / 256;
-    if (nchunks > 0)
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cb, nchunks), dim3(256), 0, s, x, ld, rows,
-                           cols, ws);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, s, ws, nchunks, cols, out,
-                       accumulate);
     SCTC_HIP_TRY(hipGetLastError());
     return SCTC_OK;
 }

@@ -172,8 +172,8 @@ extern "C" int sctc_probe_fabric(float* results_host, int32_t n_results, void* s
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(results_host, out, 10 * sizeof(float), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    hipFree(buf);
-    hipFree(out);
+    (void)hipFree(buf);
+    (void)hipFree(out);
     if (e != hipSuccess) return set_error(SCTC_ERR_HIP, "probe_fabric: %s", hipGetErrorString(e));
     return SCTC_OK;
 }
@@ -250,24 +250,24 @@ extern "C" int sctc_probe_mfma(float* results_host, int32_t n_results, void* str
     const int blocks = 256 * 3, iters = 4000;   // 3 blocks x 4 waves per CU = 3 waves per SIMD
     for (int shape = 0; shape < 4; ++shape) {   // 0,1: constant operands; 2,3: random operands
         for (int rep = 0; rep < 2; ++rep) {     // rep 0 warms up / lets the clock settle
-            hipEventRecord(e0, s);
+            (void)hipEventRecord(e0, s);
             if (shape == 0) hipLaunchKernelGGL((mfma_rate_kernel<32, false>), dim3(blocks), dim3(256), 0, s, sink, iters);
             else if (shape == 1) hipLaunchKernelGGL((mfma_rate_kernel<16, false>), dim3(blocks), dim3(256), 0, s, sink, iters);
             else if (shape == 2) hipLaunchKernelGGL((mfma_rate_kernel<32, true>), dim3(blocks), dim3(256), 0, s, sink, iters);
             else hipLaunchKernelGGL((mfma_rate_kernel<16, true>), dim3(blocks), dim3(256), 0, s, sink, iters);
-            hipEventRecord(e1, s);
-            hipEventSynchronize(e1);
+            (void)hipEventRecord(e1, s);
+            (void)hipEventSynchronize(e1);
             float ms = 0.f;
-            hipEventElapsedTime(&ms, e0, e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
             // flops: blocks * 4 waves * iters * 32 MFMAs * (2*32*32*2) [32x32x2]  or 64 MFMAs * (2*16*16*4)
             const double fl = (double)blocks * 4 * iters * ((shape & 1) == 0 ? 32.0 * 4096.0 : 64.0 * 2048.0);
             results_host[shape * 2 + 0] = (float)(fl / (ms * 1e-3) / 1e12);
             results_host[shape * 2 + 1] = ms;
         }
     }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipFree(sink);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(SCTC_ERR_HIP, "probe_mfma: %s", hipGetErrorString(e));
     return SCTC_OK;

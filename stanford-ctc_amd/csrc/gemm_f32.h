@@ -30,7 +30,13 @@ struct GemmArgs {
     float add_scale;
     int32_t relu;
     int32_t accumulate;
-    // split-K (deterministic two-pass): partials in `splitk_ws` ([splits][M][N] floats)
+    // Fused bias gradient (brnnet.py:200 deltas.sum(axis=1)): when A is row-contiguous
+    // ([K][M], the weight-gradient layout) and `colsum_a` is set, colsum_a[m] (+)= sum_k A(m,k),
+    // accumulated by the blocks of the first N tile from the A tiles they stage anyway, summed in
+    // a fixed order (`accumulate` selects += like for C).
+    float* colsum_a;        // nullable [M]
+    // split-K (deterministic two-pass): partials in `splitk_ws` ([splits][M][N] floats, then
+    // [splits][M] column-sum partials)
     float* splitk_ws;
     int32_t splits;
 };

@@ -93,6 +93,13 @@ __global__ __launch_bounds__(NTHREADS, TileCfg<BN_>::OCC) void gemm_f32_kernel(G
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // fused column sums of A (bias gradient): only the blocks of the first N tile keep them
+    constexpr int NLDA_ = (BM * BK / 4 + NTHREADS - 1) / NTHREADS;
+    const bool do_colsum = !AK && p.colsum_a != nullptr && tile_n == 0;
+    float4 asum[NLDA_];
+#pragma unroll
+    for (int q = 0; q < NLDA_; ++q) asum[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+
     if (kt_beg < kt_end) {
         // ---- global -> register staging.  Everything that does not depend on the K tile is
         // hoisted out of the K loop: per-thread base pointers and, for gathered rows, the row
@@ -179,6 +186,10 @@ __global__ __launch_bounds__(NTHREADS, TileCfg<BN_>::OCC) void gemm_f32_kernel(G
                     const int kr = f / MQ, m = 4 * (f % MQ);
                     if (tail) zero_tail(ra[q], kt * BK + kr);
                     *reinterpret_cast<float4*>(a + kr * LDA + m) = ra[q];
+                    if (do_colsum) {
+                        asum[q].x += ra[q].x; asum[q].y += ra[q].y;
+                        asum[q].z += ra[q].z; asum[q].w += ra[q].w;
+                    }
                 }
             }
         };
@@ -266,6 +277,26 @@ __global__ __launch_bounds__(NTHREADS, TileCfg<BN_>::OCC) void gemm_f32_kernel(G
             buf ^= 1;
         }
     }
+    if constexpr (!AK) {
+        if (do_colsum) {   // block-uniform; the K loop's last barrier has released the LDS tiles
+            constexpr int LDA_ = lds_stride(AK, BM), MQ_ = BM / 4;
+#pragma unroll
+            for (int q = 0; q < NLDA_; ++q) {
+                const int f = tid + NTHREADS * q;
+                *reinterpret_cast<float4*>(smem + (f / MQ_) * LDA_ + 4 * (f % MQ_)) = asum[q];
+            }
+            __syncthreads();
+            if (tid < BM && m0 + tid < M) {
+                float v = 0.f;
+#pragma unroll
+                for (int kr = 0; kr < BK; ++kr) v += smem[kr * LDA_ + tid];   // fixed order
+                if (p.splits > 1)
+                    p.splitk_ws[(int64_t)p.splits * M * N + (int64_t)blockIdx.y * M + m0 + tid] = v;
+                else
+                    p.colsum_a[m0 + tid] = p.accumulate ? p.colsum_a[m0 + tid] + v : v;
+            }
+        }
+    }
 
     // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool partial = p.splits > 1;
@@ -321,6 +352,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p)
         const int row = (int)(i / p.N), col = (int)(i % p.N);
         p.C[(int64_t)row * p.ldc + col] = gemm_epilogue(p, v, row, col);
     }
+    if (p.colsum_a && !p.a_kcontig) {
+        const float* part = p.splitk_ws + (int64_t)p.splits * total;
+        for (int m = blockIdx.x * 256 + threadIdx.x; m < p.M; m += gridDim.x * 256) {
+            float v = 0.f;
+            for (int z = 0; z < p.splits; ++z) v += part[(int64_t)z * p.M + m];   // fixed order
+            p.colsum_a[m] = p.accumulate ? p.colsum_a[m] + v : v;
+        }
+    }
 }
 
 // 96-column tiles when they waste at least 2 % fewer padded columns than 128-column tiles
@@ -353,7 +392,7 @@ int64_t gemm_plan_splits(int M, int N, int K, int* splits)
         }
     }
     *splits = s;
-    return s > 1 ? (int64_t)s * M * N : 0;
+    return s > 1 ? (int64_t)s * M * (N + 1) : 0;   // + [splits][M] column-sum partials
 }
 
 template <int BN_>

@@ -97,7 +97,7 @@ extern "C" int sctc_selftest(void* stream)
     int h = -1;
     hipError_t e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-    hipFree(d);
+    (void)hipFree(d);
     if (e != hipSuccess) return set_error(SCTC_ERR_HIP, "selftest: %s", hipGetErrorString(e));
     return h;
 }
