@@ -33,12 +33,14 @@
 // identically for W and x, so both operands are 16-byte vector loads.
 #include "common.h"
 #include "recurrent.h"
+#include "xlane.h"
 
 namespace sctc {
 
 typedef void (*RecKernel)(RecArgs);
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 static constexpr unsigned long long SPIN_TIMEOUT_TICKS = 300000000ull;  // 3 s of the 100 MHz clock
 
@@ -513,6 +515,199 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Small-batch variant (1..4 utterances: the reference's minibatch-1 mode).  With one utterance
+// a step is a 16 x H matrix-vector product per workgroup (0.1 us of VALU work) and the whole
+// step is hand-off latency, so the exchange protocol changes:
+//   * no flags, no store drain: the exchange buffer ([step*4 + utterance][H], row-major) is
+//     filled with a sentinel bit pattern (0xFFFFFFFF, a NaN no arithmetic here produces) before
+//     the launch, every address is written once, and consumers re-read a row with L2-bypassing
+//     (sc1) loads until no dword is the sentinel: ONE fabric hop per step instead of three
+//     (data ack -> flag -> data fetch).  The bypass traffic is 7 KiB per workgroup, utterance and
+//     poll -- affordable only at this batch size, which is why the larger kernels use flags;
+//   * weights live in registers (2 rows x H/32 values per thread), the previous state is staged
+//     once per step into LDS by the polling waves (one wave per utterance) and read as
+//     broadcasts; fp32 FMAs + a DPP reduction over the 32 K slices replace the MFMA tile that
+//     would be 15/16 padding.
+// NK = H/32 values per thread and row.
+static constexpr unsigned XSENT = 0xffffffffu;
+static constexpr int SB_MAX = 4;   // utterances
+
+template <int NK>
+__global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    float* xs = reinterpret_cast<float*>(lds4);   // [2 parities][SB_MAX][Hp]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x & 1, wg = blockIdx.x >> 1;
+    const int Hp = p.Hp;
+    const int rg = tid >> 5, ks = tid & 31;          // row pair, K slice
+    const int row0 = wg * 16 + 2 * rg;               // this thread's two output units
+    const bool owner = ks == 31;                     // holds the reduced sums after the DPP tree
+
+    // ---- stationary weights in registers: w[r][i] = Wop[row0 + r][32 i + ks]
+    float w0[NK], w1[NK];
+    {
+        const float* W = p.W[g];
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const int k = 32 * i + ks;
+            if (!p.transpose) {
+                w0[i] = W[(int64_t)row0 * p.ldw + k];
+                w1[i] = W[(int64_t)(row0 + 1) * p.ldw + k];
+            } else {
+                w0[i] = W[(int64_t)k * p.ldw + row0];
+                w1[i] = W[(int64_t)k * p.ldw + row0 + 1];
+            }
+        }
+    }
+    const bool desc = p.descending[g] != 0;
+    const float* pre = p.pre[g];
+    const float* act = p.act[g];
+    float* out = p.out[g];
+    const int64_t ld = p.ld;
+    const float hi = p.max_act > 0.f ? p.max_act : INFINITY;
+    unsigned* err = p.counters + 2;
+    float* xg = p.xbuf + (size_t)g * p.n_xrows * Hp;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        xg, 0, (int)((size_t)p.n_xrows * Hp * sizeof(float)), 0x00020000);
+    int Tb[SB_MAX];
+#pragma unroll
+    for (int b = 0; b < SB_MAX; ++b) Tb[b] = b < p.B ? p.T_b[b] : 0;   // sorted, longest first
+    constexpr int NQ = (NK * 32 / 4 + 63) / 64;      // float4 loads per lane for one state row
+    const int n4 = Hp >> 2;
+
+    const int dbg_sel = (p.debug && g == 0 && tid == 0) ? (wg == 0 ? 0 : (wg == (Hp >> 4) - 1 ? 1 : -1)) : -1;
+    auto stamp = [&](int j, int k) {
+        if (dbg_sel >= 0 && j >= 64 && j < 80)
+            p.debug[(dbg_sel * 16 + (j - 64)) * 8 + k] = (unsigned)clock64();
+    };
+
+    for (int j = 0; j < p.Tmax; ++j) {
+        stamp(j, 0);
+        int nb = 0;   // active utterances at this step (a prefix, utterances are sorted by length)
+#pragma unroll
+        for (int b = 0; b < SB_MAX; ++b) nb += j < Tb[b] ? 1 : 0;
+        if (nb == 0) break;
+        // per-frame additive term and mask source of the owners (independent of the recurrence)
+        float2 pre2[SB_MAX], act2[SB_MAX];
+        int64_t orow[SB_MAX];
+#pragma unroll
+        for (int b = 0; b < SB_MAX; ++b) {
+            pre2[b] = make_float2(0.f, 0.f);
+            act2[b] = make_float2(0.f, 0.f);
+            orow[b] = 0;
+            if (b < nb) {
+                const int t = desc ? Tb[b] - 1 - j : j;
+                orow[b] = (int64_t)p.rowbase[t] + b;
+                if (owner) {
+                    pre2[b] = *reinterpret_cast<const float2*>(pre + orow[b] * ld + row0);
+                    if (act) act2[b] = *reinterpret_cast<const float2*>(act + orow[b] * ld + row0);
+                }
+            }
+        }
+        float s0[SB_MAX], s1[SB_MAX];
+#pragma unroll
+        for (int b = 0; b < SB_MAX; ++b) s0[b] = s1[b] = 0.f;
+        if (j > 0) {
+            float* xcur = xs + (size_t)(j & 1) * SB_MAX * Hp;
+            // ---- wave b fetches utterance b's previous state row: re-read until complete
+            if (wave < nb) {
+                const unsigned rowoff = (unsigned)(4 * (j - 1) + wave) * (unsigned)Hp * 4u;
+                u32x4 v[NQ];
+                const unsigned long long t0 = wall_clock64();
+                unsigned spins = 0;
+                for (;;) {
+#pragma unroll
+                    for (int c = 0; c < NQ; ++c) {
+                        const int item = min(c * 64 + lane, n4 - 1);
+                        v[c] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (unsigned)item * 16u, rowoff, 16 /* sc1 */);
+                    }
+                    bool ok = true;
+#pragma unroll
+                    for (int c = 0; c < NQ; ++c)
+                        ok = ok && v[c][0] != XSENT && v[c][1] != XSENT && v[c][2] != XSENT && v[c][3] != XSENT;
+                    if (__all(ok)) break;
+                    if ((++spins & 255u) == 0) {
+                        bool give_up = false;
+                        if (lane == 0) {
+                            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                                give_up = true;
+                            else if (wall_clock64() - t0 > SPIN_TIMEOUT_TICKS) {
+                                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                give_up = true;
+                            }
+                        }
+                        if (__any(give_up)) break;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NQ; ++c) {
+                    const int item = c * 64 + lane;
+                    if (item < n4)
+                        *reinterpret_cast<u32x4*>(xcur + (size_t)wave * Hp + 4 * item) = v[c];
+                }
+            }
+            __syncthreads();
+            stamp(j, 1);
+            // ---- 2 x (H/32) FMAs per utterance; lanes of a K-slice group read consecutive floats,
+            // the two row pairs of a wave read the same addresses (LDS broadcast)
+#pragma unroll
+            for (int b = 0; b < SB_MAX; ++b) {
+                if (b < nb) {
+                    const float* xb = xcur + (size_t)b * Hp + ks;
+                    float a0 = 0.f, a1 = 0.f, c0 = 0.f, c1 = 0.f;   // two chains per row: shorter FMA dependency
+#pragma unroll
+                    for (int i = 0; i + 1 < NK; i += 2) {
+                        const float x0 = xb[32 * i], x1 = xb[32 * (i + 1)];
+                        a0 = fmaf(w0[i], x0, a0);
+                        a1 = fmaf(w1[i], x0, a1);
+                        c0 = fmaf(w0[i + 1], x1, c0);
+                        c1 = fmaf(w1[i + 1], x1, c1);
+                    }
+                    if (NK & 1) {
+                        const float x0 = xb[32 * (NK - 1)];
+                        a0 = fmaf(w0[NK - 1], x0, a0);
+                        a1 = fmaf(w1[NK - 1], x0, a1);
+                    }
+                    float r0 = a0 + c0, r1 = a1 + c1;
+                    // sum over the 32 K slices = two DPP rows: lane 31 / 63 end up with the total
+                    r0 = dpp_add<DPP_ROW_SHR1, 0xF>(r0); r1 = dpp_add<DPP_ROW_SHR1, 0xF>(r1);
+                    r0 = dpp_add<DPP_ROW_SHR2, 0xF>(r0); r1 = dpp_add<DPP_ROW_SHR2, 0xF>(r1);
+                    r0 = dpp_add<DPP_ROW_SHR4, 0xF>(r0); r1 = dpp_add<DPP_ROW_SHR4, 0xF>(r1);
+                    r0 = dpp_add<DPP_ROW_SHR8, 0xF>(r0); r1 = dpp_add<DPP_ROW_SHR8, 0xF>(r1);
+                    r0 = dpp_add<DPP_ROW_BCAST15, 0xA>(r0); r1 = dpp_add<DPP_ROW_BCAST15, 0xA>(r1);
+                    s0[b] = r0;
+                    s1[b] = r1;
+                }
+            }
+            stamp(j, 2);
+        }
+        if (owner) {
+#pragma unroll
+            for (int b = 0; b < SB_MAX; ++b) {
+                if (b < nb) {
+                    float2 o;
+                    if (!act) {
+                        o.x = fminf(fmaxf(pre2[b].x + s0[b], 0.f), hi);
+                        o.y = fminf(fmaxf(pre2[b].y + s1[b], 0.f), hi);
+                    } else {
+                        o.x = (act2[b].x > 0.f && act2[b].x < hi) ? pre2[b].x + s0[b] : 0.f;
+                        o.y = (act2[b].y > 0.f && act2[b].y < hi) ? pre2[b].y + s1[b] : 0.f;
+                    }
+                    *reinterpret_cast<float2*>(out + orow[b] * ld + row0) = o;
+                    // publish: write-through, self-validating (no flag, no drain)
+                    __builtin_amdgcn_raw_buffer_store_b64(
+                        (u32x2){__float_as_uint(o.x), __float_as_uint(o.y)}, xrsrc, (unsigned)row0 * 4u,
+                        (unsigned)(4 * j + b) * (unsigned)Hp * 4u, 16 /* sc1 */);
+                }
+            }
+        }
+        stamp(j, 3);
+    }
+}
+
 size_t recurrent_xbuf_floats(int Hp, int64_t max_xrows)
 {
     return (size_t)2 * (size_t)max_xrows * Hp;  // one chunk-major state copy per direction
@@ -560,6 +755,28 @@ int launch_recurrent(const RecArgs& a, hipStream_t stream)
                          "has %d CUs", 2 * nwg, cus);
     const int ntiles = (a.B + 15) / 16;
     SCTC_HIP_TRY(hipMemsetAsync(a.counters, 0, REC_COUNTER_WORDS * sizeof(unsigned), stream));
+    if (a.B <= SB_MAX && a.variant != 1 && (int64_t)4 * a.Tmax <= a.n_xrows) {
+        RecKernel sk = nullptr;
+        switch (a.Hp / 32) {
+            case 16: sk = brnn_recurrent_s_kernel<16>; break;   // H = 512
+            case 32: sk = brnn_recurrent_s_kernel<32>; break;   // H = 1024
+            case 57: sk = brnn_recurrent_s_kernel<57>; break;   // H = 1824
+            case 64: sk = brnn_recurrent_s_kernel<64>; break;   // H = 2048
+            default: break;
+        }
+        if (sk) {
+            // sentinel-fill the exchange rows this launch will write (both directions)
+            for (int g = 0; g < 2; ++g)
+                SCTC_HIP_TRY(hipMemsetAsync(a.xbuf + (size_t)g * a.n_xrows * a.Hp, 0xFF,
+                                            (size_t)4 * a.Tmax * a.Hp * sizeof(float), stream));
+            const size_t smem = sizeof(float) * 2 * SB_MAX * a.Hp;
+            SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(sk, dim3(2 * nwg), dim3(256), smem, stream, a);
+            SCTC_HIP_TRY(hipGetLastError());
+            return SCTC_OK;
+        }
+    }
     if (ntiles == 2 && a.variant != 1 && 4 * nwg <= 2 * cus && (4 * nwg) % 8 == 0) {
         // two chains per CU; NREG keeps the LDS share of the slab at <= 76 KiB per workgroup
         RecKernel qk = nullptr;

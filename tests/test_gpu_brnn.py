@@ -357,3 +357,59 @@ def test_recurrent_two_chain_kernel_layer_sizes(mods, monkeypatch, H):
     with np.errstate(all="ignore"):
         c_ref, _, _, _ = obrnn.cost_and_grad(params, datas[20], labs[20], TL, 20.0)
     assert costs[20] == pytest.approx(c_ref, rel=1e-4)
+
+
+@pytest.mark.parametrize("B", [1, 3, 4])
+def test_recurrent_small_batch_kernel_vs_oracle(mods, monkeypatch, B):
+    """1..4 utterances run the sentinel-exchange / register-weight recurrent kernel
+    (recurrent.hip, brnn_recurrent_s_kernel): ragged minibatch at H=512 against the float64
+    oracle and against the flag-based MFMA kernel (SCTC_REC_VARIANT=1)"""
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(100 + B)
+    D, A, H, NL, TL = 40, 33, 512, 2, 1
+    Ts = [37, 12, 1, 25][:B]
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 8)).astype(np.int32) for T in Ts]
+    with np.errstate(all="ignore"):
+        costs_ref, g_ref, skips_ref, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+    net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
+    costs, _, skips = net.costAndGradBatch(datas, labs)
+    np.testing.assert_array_equal(skips, skips_ref)
+    np.testing.assert_allclose(costs[~skips_ref], costs_ref[~skips_ref], rtol=1e-4)
+    check_grads(net, g_ref, NL)
+    g_s = _all_grads(net, NL)
+    # run-to-run reproducibility (fixed summation order, no arrival-order dependence)
+    net.costAndGradBatch(datas, labs)
+    for a, b in zip(g_s, _all_grads(net, NL)):
+        np.testing.assert_array_equal(a, b)
+    monkeypatch.setenv("SCTC_REC_VARIANT", "1")
+    net1 = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
+    costs1, _, _ = net1.costAndGradBatch(datas, labs)
+    np.testing.assert_allclose(costs, costs1, rtol=1e-6)
+    for a, b in zip(g_s, _all_grads(net1, NL)):
+        assert rel(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("H", [1824, 2048, 1024])
+def test_recurrent_small_batch_kernel_layer_sizes(mods, monkeypatch, H):
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(7 * H)
+    D, A, NL, TL = 32, 33, 2, 1
+    Ts = [40, 33]
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 8)).astype(np.int32) for T in Ts]
+    net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=2)
+    costs, _, skips = net.costAndGradBatch(datas, labs)
+    assert not skips.any()
+    g_s = _all_grads(net, NL)
+    monkeypatch.setenv("SCTC_REC_VARIANT", "1")
+    net1 = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=2)
+    costs1, _, _ = net1.costAndGradBatch(datas, labs)
+    np.testing.assert_allclose(costs, costs1, rtol=1e-5)
+    for a, b in zip(g_s, _all_grads(net1, NL)):
+        assert rel(a, b) < 1e-4
+    with np.errstate(all="ignore"):
+        c_ref, _, _, _ = obrnn.cost_and_grad(params, datas[1], labs[1], TL, 20.0)
+    assert costs[1] == pytest.approx(c_ref, rel=1e-4)
