@@ -347,7 +347,7 @@ def main():
              "brnn_small": lambda: sec_brnn("cfg2", 1, 0),
              "brnn4": lambda: sec_brnn("cfg4", 32, None),
              "brnn5": lambda: sec_brnn("cfg5", 1, None), "brnn5b": lambda: sec_brnn("cfg5", 8, None),
-             "brnn2": lambda: sec_brnn("cfg2", 1, None), "brnn1u": lambda: sec_brnn("cfg3", 1, None)}
+             "brnn2": lambda: sec_brnn("cfg2", 1, None), "brnnB": lambda: [sec_brnn("cfg3", b, None) for b in (1, 2, 4, 8, 16, 32)], "brnn1u": lambda: sec_brnn("cfg3", 1, None)}
     for name in want:
         print("==== %s" % name, flush=True)
         try:
