@@ -194,6 +194,9 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
         allow[jj] = ok && idx >= 1 && lab[jj] != prev;
         valid_lab[jj] = ok;
     }
+    R allowf[KH];
+#pragma unroll
+    for (int jj = 0; jj < KH; ++jj) allowf[jj] = allow[jj] ? (R)1 : (R)0;
     // blank states K*lane + 2*jj exist while 2*(KH*lane+jj) <= 2U
     bool valid_blk[KH];
 #pragma unroll
@@ -304,9 +307,62 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
                 for (int i = 0; i < PF; ++i) {
                     ybv[i] = bcast(ycur[i], blank);
 #pragma unroll
-                    for (int jj = 0; jj < KH; ++jj) ylv[i][jj] = gather(ycur[i], lab[jj]);
+                    for (int jj = 0; jj < KH; ++jj) {
+                        // every lane takes part in the gather (cross-lane op); states beyond the
+                        // label row then multiply by 0
+                        const R gl = gather(ycur[i], lab[jj]);
+                        ylv[i][jj] = valid_lab[jj] ? gl : (R)0;
+                    }
                 }
             }
+            // Frames whose band starts at state 0 (L <= 2(T - tau): all but the last ~U frames)
+            // need no band test, and the states beyond the label row stay exactly zero because
+            // their label probability was zeroed at gather time (a blank state beyond the row
+            // only ever adds zeros).  For a whole block of such frames the step is 2 DPP moves,
+            // 5 float64 operations per state pair and the row store -- no compares or selects on
+            // the recursion's dependency chain.  `in + allow*below` as one fma rounds like the add.
+            const bool fast = PREG && (tb + PF - 1 < T) && (L <= 2 * (T - (tb + PF - 1)));
+            if (fast) {
+                if constexpr (PREG) {
+#pragma unroll
+                    for (int i = 0; i < PF; ++i) {
+                        const int tau = tb + i;
+                        if (skip) continue;
+                        const R yb = ybv[i];
+                        const R prev_last = lane_shr1(a[K - 1]);
+                        R n[K];
+#pragma unroll
+                        for (int jj = 0; jj < KH; ++jj) {
+                            const R below = jj == 0 ? prev_last : a[2 * jj - 1];
+                            n[2 * jj] = (a[2 * jj] + below) * yb;
+                            n[2 * jj + 1] = fma(below, allowf[jj], a[2 * jj + 1] + a[2 * jj]) * ylv[i][jj];
+                        }
+                        if ((tau % RS) == 0) {
+                            R loc = n[0];
+#pragma unroll
+                            for (int j = 1; j < K; ++j) loc += n[j];
+                            const R c = wave_sum(loc);
+                            if (c == (R)0) {
+                                skip = 1;
+                            } else {
+                                const R r = (R)1 / c;
+#pragma unroll
+                                for (int j = 0; j < K; ++j) a[j] = n[j] * r;
+                                if (lane == (nscaled & 63)) rslot = r;
+                                ++nscaled;
+                                if ((nscaled & 63) == 0) {
+                                    ll -= log((double)rslot);
+                                    rslot = (R)1;
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < K; ++j) a[j] = n[j];
+                        }
+                        if (!skip) store_row(tau, a);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int tau = tb + i;
@@ -360,6 +416,7 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
                     }
                     if (!skip) store_row(tau, a);
                 }
+            }
             }
 #pragma unroll
             for (int i = 0; i < PF; ++i)

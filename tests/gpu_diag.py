@@ -295,12 +295,12 @@ def sec_brnn(cfgname="cfg3", B=32, sync=None):
     del net
 
 
-def sec_recdbg(sync=0):
+def sec_recdbg(sync=0, B=32):
     """per-step timeline of the recurrent kernel (workgroups 0 and last of direction 0)"""
     from nnets import brnnet
     os.environ["SCTC_REC_DEBUG"] = "1"
     os.environ["SCTC_REC_SYNC"] = str(sync)
-    D, A, H, NL, TL, T, U, B = 483, 33, 1824, 5, 3, 200, 20, 32
+    D, A, H, NL, TL, T, U = 483, 33, 1824, 5, 3, 200, 20
     np.random.seed(0)
     net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B)
     net.initParams()
@@ -343,7 +343,7 @@ def main():
     table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "gemmstamp": sec_gemmstamp, "gemmk": sec_gemmk, "twostream": sec_twostream, "fabric": sec_fabric, "mfmarate": sec_mfmarate, "ctc": sec_ctc,
              "brnn": lambda: sec_brnn("cfg3", 32, 0),
              "brnn1": lambda: sec_brnn("cfg3", 32, 1),
-             "recdbg": lambda: sec_recdbg(0), "recdbg1": lambda: sec_recdbg(1),
+             "recdbg": lambda: sec_recdbg(0), "recdbg1": lambda: sec_recdbg(1), "recdbgB1": lambda: sec_recdbg(1, 1),
              "brnn_small": lambda: sec_brnn("cfg2", 1, 0),
              "brnn4": lambda: sec_brnn("cfg4", 32, None),
              "brnn5": lambda: sec_brnn("cfg5", 1, None), "brnn5b": lambda: sec_brnn("cfg5", 8, None),
