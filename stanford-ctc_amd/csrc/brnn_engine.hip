@@ -204,6 +204,10 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
             sk = std::max<int64_t>(sk, gemm_plan_splits(d.Hp, d.Hp, (int)F, &sp));
         }
     }
+    // small minibatches (few row tiles) split K in the forward / delta-propagation GEMMs as well:
+    // blocks x splits stays below ~2 rounds of resident blocks, i.e. <= 2*1024 tiles of 128x128
+    sk = std::max<int64_t>(sk, std::min<int64_t>((int64_t)2 * 1024 * 128 * 128,
+                                                 (int64_t)64 * F * (std::max(d.Hp, d.Ap) + 1)));
     float* splitk_ws = sk ? f(sk) : nullptr;
     float* xbuf = d.TL > 0 ? f((int64_t)recurrent_xbuf_floats(d.Hp, recurrent_xrows_bound(F, F))) : nullptr;
     unsigned* counters = ar.take<unsigned>(REC_COUNTER_WORDS);
@@ -345,6 +349,17 @@ static GemmArgs gemm_defaults()
     return g;
 }
 
+// deterministic split-K when the output has too few tiles to fill the machine (small minibatch)
+static void maybe_split(const sctc_brnn* h, GemmArgs& g)
+{
+    int sp = 1;
+    const int64_t need = gemm_plan_splits(g.M, g.N, g.K, &sp);
+    if (sp > 1 && h->splitk_ws && need <= h->splitk_floats) {
+        g.splits = sp;
+        g.splitk_ws = h->splitk_ws;
+    }
+}
+
 static const float* tensor_ptr(const sctc_brnn* h, const float* base, int idx)
 {
     return base + h->tinfo[idx].offset;
@@ -379,6 +394,7 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
         g.C = dst;
         g.ldc = LD(outp);
         g.relu = (i <= h->NL && i != h->TL) ? 1 : 0;             // brnnet.py:155-157
+        maybe_split(h, g);
         SCTC_TRY(launch_gemm_f32(g, s));
         if (i == h->TL) {
             pt.begin(SCTC_PHASE_FWD_REC);
@@ -541,6 +557,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             g.C = d_out;
             g.ldc = LD(inp);
             if (i != h->TL) { g.mask = h->act[i]; g.ldmask = LD(h->Hp); }
+            maybe_split(h, g);
             SCTC_TRY(launch_gemm_f32(g, s));
         }
         if (i == h->TL) {
