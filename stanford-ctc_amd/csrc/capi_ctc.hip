@@ -40,13 +40,15 @@ int ctc_make_plan(int B, int A, int blank, const int32_t* T_b, const int32_t* U_
         n_labels += U_b[b];
         frames += T_b[b];
     }
-    const int K = ctc_states_per_lane(max_L);
+    int W = 1;
+    const int K = ctc_lattice_shape(max_L, &W);
     SCTC_CHECK_ARG(K > 0, "ctc: label sequence too long (2U+1 = %d > 2048)", max_L);
     plan->B = B;
     plan->A = A;
     plan->blank = blank;
     plan->K = K;
-    plan->lp = 64 * K;
+    plan->W = W;
+    plan->lp = 64 * W * K;
     plan->max_T = max_T;
     plan->lat_elems = frames * plan->lp;
     plan->n_labels = n_labels;
@@ -121,7 +123,7 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
     la.beta = d_beta;
     la.ll = d_ll;
     la.skip2 = d_skip2;
-    SCTC_TRY(launch_ctc_lattice<R>(la, plan.B, plan.K, stream));
+    SCTC_TRY(launch_ctc_lattice<R>(la, plan.B, plan.K, plan.W, stream));
 
     CtcGradArgs<R> ga;
     ga.utts = d_utts;

@@ -48,9 +48,11 @@ struct CtcGradArgs {
     int32_t* skip;  // [B]
 };
 
-int ctc_states_per_lane(int max_L);  // K in {2,4,8,16,32}; 0 if 2U+1 > 2048
+// K states per lane and W waves per (utterance, pass) for rows of up to max_L states;
+// returns K (0 if 2U+1 > 2048), *waves = W; the lattice row stride is 64*W*K
+int ctc_lattice_shape(int max_L, int* waves);
 template <typename RI>
-int launch_ctc_lattice(const CtcLatticeArgs<RI>& a, int B, int K, hipStream_t stream);
+int launch_ctc_lattice(const CtcLatticeArgs<RI>& a, int B, int K, int W, hipStream_t stream);
 template <typename RI>
 int launch_ctc_grad(const CtcGradArgs<RI>& a, int B, int max_T, hipStream_t stream);
 int launch_softmax_rows(const float* x, float* y, int64_t rows, int A, int64_t ld,
@@ -61,7 +63,7 @@ int launch_argmax_rows(const void* y, int dtype, int32_t* best, int64_t rows, in
 // Host-side driver shared by the C ABI and the BRNN engine: lays the descriptors
 // out in `ws`, uploads them and launches lattice + grad.
 struct CtcPlan {
-    int B = 0, A = 0, blank = 0, K = 0, lp = 0, max_T = 0;
+    int B = 0, A = 0, blank = 0, K = 0, W = 1, lp = 0, max_T = 0;   // lp = 64*W*K
     int64_t lat_elems = 0;  // elements per lattice (alpha or beta)
     int64_t n_labels = 0;
     size_t bytes = 0;       // workspace bytes for this plan (float64 lattices)

@@ -152,9 +152,14 @@ __device__ __forceinline__ int64_t frame_row(const CtcUtt& u, const int32_t* row
 // RS = 1, the reference's schedule, for float64 probabilities): llForward is the log of the
 // last frame's mass minus the logs of the applied factors, the same number, while the
 // 64-lane reduction + division leave the per-step dependency chain.
-template <typename RI, int K, int NA>
-__global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
+template <typename RI, int K, int NA, int W>
+__global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
 {
+    // W waves share one (utterance, pass): state s lives in global lane gl = s / K.  The two
+    // cross-wave couplings of a frame go through LDS: the neighbour state of a wave's lane 0
+    // (last state of the previous wave) and the band sum of a rescaling frame.
+    __shared__ double bnd[2][W > 1 ? W : 1];
+    __shared__ double part[2][W > 1 ? W : 1];
     using R = double;
     static_assert(K % 2 == 0 && K >= 2, "K must be even");
     constexpr int KH = K / 2;
@@ -169,7 +174,8 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
     constexpr int PF = K <= 4 ? 32 : (K <= 8 ? 16 : 8);
     const int b = blockIdx.x;
     const int dir = blockIdx.y;  // 0: alpha, 1: beta (== alpha of the reversed problem)
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x;
+    (void)wave;
     const CtcUtt u = p.utts[b];
     const int T = u.T, U = u.U, L = 2 * U + 1;
     const int LP = p.lp;  // lattice row stride (64*K)
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
     bool valid_lab[KH];
 #pragma unroll
     for (int jj = 0; jj < KH; ++jj) {
-        const int idx = KH * lane + jj;  // label index of state K*lane + 2*jj + 1
+        const int idx = KH * gl + jj;  // label index of state K*gl + 2*jj + 1
         const bool ok = idx < U;
         const int i0 = ok ? (dir ? U - 1 - idx : idx) : 0;
         lab[jj] = seq[i0];
@@ -197,10 +203,10 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
     R allowf[KH];
 #pragma unroll
     for (int jj = 0; jj < KH; ++jj) allowf[jj] = allow[jj] ? (R)1 : (R)0;
-    // blank states K*lane + 2*jj exist while 2*(KH*lane+jj) <= 2U
+    // blank states K*gl + 2*jj exist while 2*(KH*gl+jj) <= 2U
     bool valid_blk[KH];
 #pragma unroll
-    for (int jj = 0; jj < KH; ++jj) valid_blk[jj] = (KH * lane + jj) <= U;
+    for (int jj = 0; jj < KH; ++jj) valid_blk[jj] = (KH * gl + jj) <= U;
 
     const RI* probs = p.probs;
     const int64_t ld = p.ld;
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
 #ifdef SCTC_CTC_NOSTORE
         if (tau != 0x7fffffff) return;
 #endif
-        R* row = lat + (int64_t)tau * LP + (int64_t)K * lane;
+        R* row = lat + (int64_t)tau * LP + (int64_t)K * gl;
         if constexpr (K % 4 == 0) {
             typename Vec<R>::v4* dst = reinterpret_cast<typename Vec<R>::v4*>(row);
 #pragma unroll
@@ -246,6 +252,39 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
         } else {
 #pragma unroll
             for (int j = 0; j < K; ++j) row[j] = v[j];
+        }
+    };
+
+    // workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the
+    // lattice-row stores to HBM (vmcnt) in every frame
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // sum over all states of the block, identical in every lane (fixed order)
+    auto block_sum = [&](R loc, int tau) -> R {
+        const R ws = wave_sum(loc);
+        if constexpr (W == 1) {
+            return ws;
+        } else {
+            if (lane == 0) part[tau & 1][wave] = ws;
+            lds_barrier();
+            R c = part[tau & 1][0];
+#pragma unroll
+            for (int w = 1; w < W; ++w) c += part[tau & 1][w];
+            return c;
+        }
+    };
+    // last state of global lane gl - 1 as of the previous frame (all threads call, start of a frame)
+    auto shift_in = [&](const R (&v)[K], int tau) -> R {
+        R prev = lane_shr1(v[K - 1]);
+        if constexpr (W > 1) {
+            lds_barrier();
+            if (lane == 0 && wave > 0) prev = bnd[(tau - 1) & 1][wave - 1];
+        }
+        return prev;
+    };
+    // publish this wave's last state once a frame's row is final (all threads call)
+    auto shift_out = [&](const R (&v)[K], int tau) {
+        if constexpr (W > 1) {
+            if (lane == 63) bnd[tau & 1][wave] = v[K - 1];
         }
     };
 
@@ -269,8 +308,8 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
         load_frame(0, y0);
         const R yb = bcast(y0, blank);
         const R yl = gather(y0, lab[0]);
-        if (lane == 0) { a[0] = yb; a[1] = yl; }
-        const R c = wave_sum(a[0] + a[1]);
+        if (gl == 0) { a[0] = yb; a[1] = yl; }
+        const R c = block_sum(a[0] + a[1], 0);
         if (c == (R)0) {
             skip = 1;  // ZeroDivisionError at :45
         } else {
@@ -281,6 +320,7 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
             nscaled = 1;
         }
         store_row(0, a);
+        shift_out(a, 0);
     }
 
     if (!skip && empty_band) {
@@ -300,7 +340,7 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
             // For short label rows the per-state probabilities of the whole block are gathered
             // (ds_bpermute / readlane) before the serial part starts, so that the LDS-crossbar
             // latency is off the recursion's dependency chain.
-            constexpr bool PREG = K <= 4;
+            constexpr bool PREG = K <= 8;
             R ybv[PREG ? PF : 1], ylv[PREG ? PF : 1][KH];
             if constexpr (PREG) {
 #pragma unroll
@@ -329,7 +369,7 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
                         const int tau = tb + i;
                         if (skip) continue;
                         const R yb = ybv[i];
-                        const R prev_last = lane_shr1(a[K - 1]);
+                        const R prev_last = shift_in(a, tau);
                         R n[K];
 #pragma unroll
                         for (int jj = 0; jj < KH; ++jj) {
@@ -341,7 +381,7 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
                             R loc = n[0];
 #pragma unroll
                             for (int j = 1; j < K; ++j) loc += n[j];
-                            const R c = wave_sum(loc);
+                            const R c = block_sum(loc, tau);
                             if (c == (R)0) {
                                 skip = 1;
                             } else {
@@ -360,6 +400,7 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
                             for (int j = 0; j < K; ++j) a[j] = n[j];
                         }
                         if (!skip) store_row(tau, a);
+                        shift_out(a, tau);
                     }
                 }
             } else {
@@ -373,16 +414,16 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
                     const int start = L <= rem ? 0 : L - rem;
                     R yb;
                     if constexpr (PREG) yb = ybv[i]; else yb = bcast(ycur[i], blank);
-                    const R prev_last = lane_shr1(a[K - 1]);  // state K*lane - 1
+                    const R prev_last = shift_in(a, tau);  // state K*gl - 1
                     R n[K];
 #pragma unroll
                     for (int jj = 0; jj < KH; ++jj) {
-                        // blank state s = K*lane + 2*jj  (:58-62)
+                        // blank state s = K*gl + 2*jj  (:58-62)
                         const R below = jj == 0 ? prev_last : a[2 * jj - 1];
-                        const int sb = K * lane + 2 * jj;
+                        const int sb = K * gl + 2 * jj;
                         const R vb = (a[2 * jj] + below) * yb;
                         n[2 * jj] = (valid_blk[jj] && sb >= start) ? vb : (R)0;
-                        // label state s = K*lane + 2*jj + 1  (:63-68)
+                        // label state s = K*gl + 2*jj + 1  (:63-68)
                         R yl;
                         if constexpr (PREG) yl = ylv[i][jj]; else yl = gather(ycur[i], lab[jj]);
                         R in = a[2 * jj + 1] + a[2 * jj];
@@ -396,7 +437,7 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
                         R loc = n[0];
 #pragma unroll
                         for (int j = 1; j < K; ++j) loc += n[j];
-                        const R c = wave_sum(loc);
+                        const R c = block_sum(loc, tau);
                         if (c == (R)0) {
                             skip = 1;  // ZeroDivisionError at :75 (band is non-empty here)
                         } else {
@@ -415,6 +456,7 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
                         for (int j = 0; j < K; ++j) a[j] = n[j];
                     }
                     if (!skip) store_row(tau, a);
+                    shift_out(a, tau);
                 }
             }
             }
@@ -427,7 +469,7 @@ __global__ __launch_bounds__(64) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
     // factors still parked
     ll -= log((double)rslot);
     double total = wave_sum(ll);
-    if (lane == 0) {
+    if (gl == 0) {
         if (empty_band && !skip) total = -INFINITY;  // math.log(0.0)
         p.ll[2 * b + dir] = total;                   // llForward (dir 0) / llBackward (dir 1)
         p.skip2[2 * b + dir] = skip;
@@ -513,37 +555,57 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<RI> p)
 
 // ---------------------------------------------------------------- launchers
 
-template <typename RI, int K>
+template <typename RI, int K, int W>
 static int launch_lattice_k(const CtcLatticeArgs<RI>& a, int B, int NA, hipStream_t stream)
 {
-    dim3 grid(B, 2), block(64);
-    if (NA == 1) hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 1>), grid, block, 0, stream, a);
-    else if (NA == 2) hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 2>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 4>), grid, block, 0, stream, a);
+    dim3 grid(B, 2), block(64 * W);
+    if (NA == 1) hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 1, W>), grid, block, 0, stream, a);
+    else if (NA == 2) hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 2, W>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 4, W>), grid, block, 0, stream, a);
     SCTC_HIP_TRY(hipGetLastError());
     return SCTC_OK;
 }
 
-int ctc_states_per_lane(int max_L)
+// Lattice shape for label rows of up to max_L = 2U+1 states: K states per lane, W waves per
+// (utterance, pass).  Up to 256 states one wave holds everything (no cross-wave traffic); longer
+// rows are spread over 4 waves so that a frame costs K/4 as many dependent float64 operations.
+int ctc_lattice_shape(int max_L, int* waves)
 {
-    for (int k = 2; k <= 32; k *= 2)
-        if (max_L <= 64 * k) return k;
+    const char* force = getenv("SCTC_CTC_WAVES");   // diagnostics: 1 / 4
+    const int fw = force ? atoi(force) : 0;
+    if ((fw == 0 && max_L <= 256) || fw == 1) {
+        *waves = 1;
+        for (int k = 2; k <= 32; k *= 2)
+            if (max_L <= 64 * k) return k;
+        return 0;
+    }
+    *waves = 4;
+    for (int k = 2; k <= 8; k *= 2)
+        if (max_L <= 256 * k) return k;
     return 0;
 }
 
 template <typename RI>
-int launch_ctc_lattice(const CtcLatticeArgs<RI>& a, int B, int K, hipStream_t stream)
+int launch_ctc_lattice(const CtcLatticeArgs<RI>& a, int B, int K, int W, hipStream_t stream)
 {
     using R = RI;
     const int NA = a.A <= 64 ? 1 : (a.A <= 128 ? 2 : 4);
-    switch (K) {
-        case 2: return launch_lattice_k<R, 2>(a, B, NA, stream);
-        case 4: return launch_lattice_k<R, 4>(a, B, NA, stream);
-        case 8: return launch_lattice_k<R, 8>(a, B, NA, stream);
-        case 16: return launch_lattice_k<R, 16>(a, B, NA, stream);
-        case 32: return launch_lattice_k<R, 32>(a, B, NA, stream);
+    if (W == 4) {
+        switch (K) {
+            case 2: return launch_lattice_k<R, 2, 4>(a, B, NA, stream);
+            case 4: return launch_lattice_k<R, 4, 4>(a, B, NA, stream);
+            case 8: return launch_lattice_k<R, 8, 4>(a, B, NA, stream);
+        }
+    } else {
+        switch (K) {
+            case 2: return launch_lattice_k<R, 2, 1>(a, B, NA, stream);
+            case 4: return launch_lattice_k<R, 4, 1>(a, B, NA, stream);
+            case 8: return launch_lattice_k<R, 8, 1>(a, B, NA, stream);
+            case 16: return launch_lattice_k<R, 16, 1>(a, B, NA, stream);
+            case 32: return launch_lattice_k<R, 32, 1>(a, B, NA, stream);
+        }
     }
-    return set_error(SCTC_ERR_ARG, "ctc: label sequence too long (K=%d)", K);
+    return set_error(SCTC_ERR_ARG, "ctc: label sequence too long (K=%d, W=%d)", K, W);
 }
 
 template <typename R>
@@ -559,8 +621,8 @@ int launch_ctc_grad(const CtcGradArgs<R>& a, int B, int max_T, hipStream_t strea
     return SCTC_OK;
 }
 
-template int launch_ctc_lattice<float>(const CtcLatticeArgs<float>&, int, int, hipStream_t);
-template int launch_ctc_lattice<double>(const CtcLatticeArgs<double>&, int, int, hipStream_t);
+template int launch_ctc_lattice<float>(const CtcLatticeArgs<float>&, int, int, int, hipStream_t);
+template int launch_ctc_lattice<double>(const CtcLatticeArgs<double>&, int, int, int, hipStream_t);
 template int launch_ctc_grad<float>(const CtcGradArgs<float>&, int, int, hipStream_t);
 template int launch_ctc_grad<double>(const CtcGradArgs<double>&, int, int, hipStream_t);
 
