@@ -531,13 +531,13 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
 //     would be 15/16 padding.
 // NK = H/32 values per thread and row.
 static constexpr unsigned XSENT = 0xffffffffu;
-static constexpr int SB_MAX = 4;   // utterances
+static constexpr int SB_MAX = 8;   // utterances (template SB = 4 or 8)
 
-template <int NK>
+template <int NK, int SB>
 __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-    float* xs = reinterpret_cast<float*>(lds4);   // [2 parities][SB_MAX][Hp]
+    float* xs = reinterpret_cast<float*>(lds4);   // [2 parities][SB][Hp]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x & 1, wg = blockIdx.x >> 1;
@@ -572,9 +572,9 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
     float* xg = p.xbuf + (size_t)g * p.n_xrows * Hp;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         xg, 0, (int)((size_t)p.n_xrows * Hp * sizeof(float)), 0x00020000);
-    int Tb[SB_MAX];
+    int Tb[SB];
 #pragma unroll
-    for (int b = 0; b < SB_MAX; ++b) Tb[b] = b < p.B ? p.T_b[b] : 0;   // sorted, longest first
+    for (int b = 0; b < SB; ++b) Tb[b] = b < p.B ? p.T_b[b] : 0;   // sorted, longest first
     constexpr int NQ = (NK * 32 / 4 + 63) / 64;      // float4 loads per lane for one state row
     const int n4 = Hp >> 2;
 
@@ -584,17 +584,22 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
             p.debug[(dbg_sel * 16 + (j - 64)) * 8 + k] = (unsigned)clock64();
     };
 
+    // exchange row of utterance b at step j = xbase[j] + b (fetched one step ahead)
+    int xb_next = p.xbase[0], xb_cur = 0;
     for (int j = 0; j < p.Tmax; ++j) {
         stamp(j, 0);
+        const int xb_prev = xb_cur;
+        xb_cur = xb_next;
+        xb_next = p.xbase[min(j + 1, p.Tmax - 1)];
         int nb = 0;   // active utterances at this step (a prefix, utterances are sorted by length)
 #pragma unroll
-        for (int b = 0; b < SB_MAX; ++b) nb += j < Tb[b] ? 1 : 0;
+        for (int b = 0; b < SB; ++b) nb += j < Tb[b] ? 1 : 0;
         if (nb == 0) break;
         // per-frame additive term and mask source of the owners (independent of the recurrence)
-        float2 pre2[SB_MAX], act2[SB_MAX];
-        int64_t orow[SB_MAX];
+        float2 pre2[SB], act2[SB];
+        int64_t orow[SB];
 #pragma unroll
-        for (int b = 0; b < SB_MAX; ++b) {
+        for (int b = 0; b < SB; ++b) {
             pre2[b] = make_float2(0.f, 0.f);
             act2[b] = make_float2(0.f, 0.f);
             orow[b] = 0;
@@ -607,14 +612,14 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
                 }
             }
         }
-        float s0[SB_MAX], s1[SB_MAX];
+        float s0[SB], s1[SB];
 #pragma unroll
-        for (int b = 0; b < SB_MAX; ++b) s0[b] = s1[b] = 0.f;
+        for (int b = 0; b < SB; ++b) s0[b] = s1[b] = 0.f;
         if (j > 0) {
-            float* xcur = xs + (size_t)(j & 1) * SB_MAX * Hp;
+            float* xcur = xs + (size_t)(j & 1) * SB * Hp;
             // ---- wave b fetches utterance b's previous state row: re-read until complete
-            if (wave < nb) {
-                const unsigned rowoff = (unsigned)(4 * (j - 1) + wave) * (unsigned)Hp * 4u;
+            for (int bb = wave; bb < nb; bb += 4) {   // 4 waves, up to SB rows
+                const unsigned rowoff = (unsigned)(xb_prev + bb) * (unsigned)Hp * 4u;
                 u32x4 v[NQ];
                 const unsigned long long t0 = wall_clock64();
                 unsigned spins = 0;
@@ -646,7 +651,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
                 for (int c = 0; c < NQ; ++c) {
                     const int item = c * 64 + lane;
                     if (item < n4)
-                        *reinterpret_cast<u32x4*>(xcur + (size_t)wave * Hp + 4 * item) = v[c];
+                        *reinterpret_cast<u32x4*>(xcur + (size_t)bb * Hp + 4 * item) = v[c];
                 }
             }
             __syncthreads();
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
             // ---- 2 x (H/32) FMAs per utterance; lanes of a K-slice group read consecutive floats,
             // the two row pairs of a wave read the same addresses (LDS broadcast)
 #pragma unroll
-            for (int b = 0; b < SB_MAX; ++b) {
+            for (int b = 0; b < SB; ++b) {
                 if (b < nb) {
                     const float* xb = xcur + (size_t)b * Hp + ks;
                     float a0 = 0.f, a1 = 0.f, c0 = 0.f, c1 = 0.f;   // two chains per row: shorter FMA dependency
@@ -686,7 +691,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
         }
         if (owner) {
 #pragma unroll
-            for (int b = 0; b < SB_MAX; ++b) {
+            for (int b = 0; b < SB; ++b) {
                 if (b < nb) {
                     float2 o;
                     if (!act) {
@@ -700,7 +705,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
                     // publish: write-through, self-validating (no flag, no drain)
                     __builtin_amdgcn_raw_buffer_store_b64(
                         (u32x2){__float_as_uint(o.x), __float_as_uint(o.y)}, xrsrc, (unsigned)row0 * 4u,
-                        (unsigned)(4 * j + b) * (unsigned)Hp * 4u, 16 /* sc1 */);
+                        (unsigned)(xb_cur + b) * (unsigned)Hp * 4u, 16 /* sc1 */);
                 }
             }
         }
@@ -755,21 +760,22 @@ int launch_recurrent(const RecArgs& a, hipStream_t stream)
                          "has %d CUs", 2 * nwg, cus);
     const int ntiles = (a.B + 15) / 16;
     SCTC_HIP_TRY(hipMemsetAsync(a.counters, 0, REC_COUNTER_WORDS * sizeof(unsigned), stream));
-    if (a.B <= SB_MAX && a.variant != 1 && (int64_t)4 * a.Tmax <= a.n_xrows) {
+    // measured at H=1824: 2.5 us per step for one utterance + ~1.2 us per further one (VALU FMAs),
+    // against 7.4 us for the flag/MFMA kernel: worth it up to 5 utterances
+    if (a.B <= 5 && a.variant != 1) {
         RecKernel sk = nullptr;
+        const bool s4 = a.B <= 4;
         switch (a.Hp / 32) {
-            case 16: sk = brnn_recurrent_s_kernel<16>; break;   // H = 512
-            case 32: sk = brnn_recurrent_s_kernel<32>; break;   // H = 1024
-            case 57: sk = brnn_recurrent_s_kernel<57>; break;   // H = 1824
-            case 64: sk = brnn_recurrent_s_kernel<64>; break;   // H = 2048
+            case 16: sk = s4 ? brnn_recurrent_s_kernel<16, 4> : brnn_recurrent_s_kernel<16, 8>; break;   // H = 512
+            case 32: sk = s4 ? brnn_recurrent_s_kernel<32, 4> : brnn_recurrent_s_kernel<32, 8>; break;   // H = 1024
+            case 57: sk = s4 ? brnn_recurrent_s_kernel<57, 4> : brnn_recurrent_s_kernel<57, 8>; break;   // H = 1824
+            case 64: sk = s4 ? brnn_recurrent_s_kernel<64, 4> : brnn_recurrent_s_kernel<64, 8>; break;   // H = 2048
             default: break;
         }
         if (sk) {
-            // sentinel-fill the exchange rows this launch will write (both directions)
-            for (int g = 0; g < 2; ++g)
-                SCTC_HIP_TRY(hipMemsetAsync(a.xbuf + (size_t)g * a.n_xrows * a.Hp, 0xFF,
-                                            (size_t)4 * a.Tmax * a.Hp * sizeof(float), stream));
-            const size_t smem = sizeof(float) * 2 * SB_MAX * a.Hp;
+            // sentinel-fill the exchange rows (both directions)
+            SCTC_HIP_TRY(hipMemsetAsync(a.xbuf, 0xFF, (size_t)2 * a.n_xrows * a.Hp * sizeof(float), stream));
+            const size_t smem = sizeof(float) * 2 * (s4 ? 4 : 8) * a.Hp;
             SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL(sk, dim3(2 * nwg), dim3(256), smem, stream, a);

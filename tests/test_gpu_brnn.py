@@ -362,15 +362,15 @@ def test_recurrent_two_chain_kernel_layer_sizes(mods, monkeypatch, H):
     assert costs[20] == pytest.approx(c_ref, rel=1e-4)
 
 
-@pytest.mark.parametrize("B", [1, 3, 4])
+@pytest.mark.parametrize("B", [1, 3, 4, 5])
 def test_recurrent_small_batch_kernel_vs_oracle(mods, monkeypatch, B):
-    """1..4 utterances run the sentinel-exchange / register-weight recurrent kernel
+    """1..5 utterances run the sentinel-exchange / register-weight recurrent kernel
     (recurrent.hip, brnn_recurrent_s_kernel): ragged minibatch at H=512 against the float64
     oracle and against the flag-based MFMA kernel (SCTC_REC_VARIANT=1)"""
     _, brnnet, obrnn, _ = mods
     rs = np.random.RandomState(100 + B)
     D, A, H, NL, TL = 40, 33, 512, 2, 1
-    Ts = [37, 12, 1, 25][:B]
+    Ts = [37, 12, 1, 25, 30, 9, 37, 18][:B]
     params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
     datas = [rs.randn(D, T) for T in Ts]
     labs = [rs.randint(1, A, size=max(1, T // 8)).astype(np.int32) for T in Ts]
