@@ -531,7 +531,6 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
 //     would be 15/16 padding.
 // NK = H/32 values per thread and row.
 static constexpr unsigned XSENT = 0xffffffffu;
-static constexpr int SB_MAX = 8;   // utterances (template SB = 4 or 8)
 
 template <int NK, int SB>
 __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
