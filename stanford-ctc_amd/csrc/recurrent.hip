@@ -712,6 +712,166 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Mid-batch variant (6..16 utterances): the one-hop sentinel exchange of the small-batch kernel
+// with the matrix cores of the big ones.  A workgroup owns 16 output units; its 16 x H weight
+// slab lives in REGISTERS as MFMA A fragments (4 waves = 4 K quarters), because the LDS is
+// needed for the staged state: the polling waves (rows round-robin over the 4 waves) re-read
+// the previous state rows ([xbase[step] + utterance][H], write-through, sentinel-validated,
+// L2-bypassing) into LDS, from where every wave takes its B fragments as 16-byte reads.
+// NCQ = ceil(H/16/4) chunks per wave.
+template <int NCQ>
+__global__ __launch_bounds__(256, 1) void brnn_recurrent_m_kernel(RecArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x & 1, wg = blockIdx.x >> 1;
+    const int Hp = p.Hp, nch = Hp >> 4;
+    const int row0 = wg * 16;
+    const int uj = lane & 15, kq = lane >> 4;
+    const int base = nch >> 2, rem = nch & 3;
+    const int cnt = base + (wave < rem ? 1 : 0);
+    const int c_beg = wave * base + min(wave, rem);
+    const int xld = Hp + 4;                                  // LDS row stride (floats): conflict-free b128 reads
+    float* xs = reinterpret_cast<float*>(lds4);              // [16][xld]
+    float4* red = lds4 + (size_t)(16 * xld) / 4;             // [3][64]
+
+    // ---- stationary weights as A fragments: wf[u] = { Wop[row0 + uj][16c + 4kq + q] }_q
+    float4 wf[NCQ];
+    {
+        const float* W = p.W[g];
+#pragma unroll
+        for (int u = 0; u < NCQ; ++u) {
+            const int c = c_beg + min(u, cnt - 1);
+            float4 v;
+            if (!p.transpose) {
+                v = *reinterpret_cast<const float4*>(W + (int64_t)(row0 + uj) * p.ldw + 16 * c + 4 * kq);
+            } else {
+                const float* col = W + (int64_t)(16 * c + 4 * kq) * p.ldw + row0 + uj;
+                v.x = col[0];
+                v.y = col[p.ldw];
+                v.z = col[2 * p.ldw];
+                v.w = col[3 * p.ldw];
+            }
+            wf[u] = v;
+        }
+    }
+    const bool desc = p.descending[g] != 0;
+    const float* pre = p.pre[g];
+    const float* act = p.act[g];
+    float* out = p.out[g];
+    const int64_t ld = p.ld;
+    const float hi = p.max_act > 0.f ? p.max_act : INFINITY;
+    unsigned* err = p.counters + 2;
+    float* xg = p.xbuf + (size_t)g * p.n_xrows * Hp;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        xg, 0, (int)((size_t)p.n_xrows * Hp * sizeof(float)), 0x00020000);
+    const int uT = uj < p.B ? p.T_b[uj] : 0;                 // lane's utterance (sorted, longest first)
+    const int n4 = Hp >> 2;
+    constexpr int NQ = (NCQ * 4 + 15) / 16;                  // float4 loads per lane for one state row
+
+    int xb_next = p.xbase[0], xb_cur = 0;
+    for (int j = 0; j < p.Tmax; ++j) {
+        const int xb_prev = xb_cur;
+        xb_cur = xb_next;
+        xb_next = p.xbase[min(j + 1, p.Tmax - 1)];
+        const int nb = __builtin_amdgcn_readfirstlane(__popcll(__ballot(j < uT && kq == 0)));   // active prefix
+        const bool active = j < uT;
+        const int t = desc ? uT - 1 - j : j;
+        const int64_t orow = active ? (int64_t)p.rowbase[t] + uj : 0;
+        float4 pre4 = make_float4(0.f, 0.f, 0.f, 0.f), act4 = pre4;
+        if (wave == 0 && active) {
+            pre4 = *reinterpret_cast<const float4*>(pre + orow * ld + row0 + 4 * kq);
+            if (act) act4 = *reinterpret_cast<const float4*>(act + orow * ld + row0 + 4 * kq);
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = {0.f, 0.f, 0.f, 0.f};
+        if (j > 0) {
+            // ---- stage the previous state: rows round-robin over the waves, re-read until complete
+            for (int bb = wave; bb < nb; bb += 4) {
+                const unsigned rowoff = (unsigned)(xb_prev + bb) * (unsigned)Hp * 4u;
+                const unsigned long long t0 = wall_clock64();
+                unsigned spins = 0;
+                u32x4 v[NQ];
+                for (;;) {   // all loads of the row in flight at once, then validate
+#pragma unroll
+                    for (int c = 0; c < NQ; ++c) {
+                        const int item = min(c * 64 + lane, n4 - 1);
+                        v[c] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (unsigned)item * 16u, rowoff, 16 /* sc1 */);
+                    }
+                    bool ok = true;
+#pragma unroll
+                    for (int c = 0; c < NQ; ++c)
+                        ok = ok && v[c][0] != XSENT && v[c][1] != XSENT && v[c][2] != XSENT && v[c][3] != XSENT;
+                    if (__all(ok)) break;
+                    if ((++spins & 255u) == 0) {
+                        bool give_up = false;
+                        if (lane == 0) {
+                            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                                give_up = true;
+                            else if (wall_clock64() - t0 > SPIN_TIMEOUT_TICKS) {
+                                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                give_up = true;
+                            }
+                        }
+                        if (__any(give_up)) break;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NQ; ++c) {
+                    const int item = c * 64 + lane;
+                    if (item < n4)
+                        *reinterpret_cast<u32x4*>(xs + (size_t)bb * xld + 4 * item) = v[c];
+                }
+            }
+            __syncthreads();
+            // ---- products: B fragment of chunk c = { x[uj][16c + 4kq + q] }_q from LDS
+            const float* xrow = xs + (size_t)uj * xld + 4 * kq;
+#pragma unroll
+            for (int u = 0; u < NCQ; ++u) {
+                if (u < NCQ - 1 || cnt == NCQ) {
+                    const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * (c_beg + u));
+                    SCTC_MFMA4(acc, wf[u], x)
+                }
+            }
+            if (wave != 0) {
+                const f32x4 sres = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                red[(wave - 1) * 64 + lane] = make_float4(sres[0], sres[1], sres[2], sres[3]);
+            }
+            __syncthreads();
+        }
+        if (wave == 0 && active) {
+            float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j > 0) {
+                const float4 r1 = red[lane], r2 = red[64 + lane], r3 = red[128 + lane];
+                const f32x4 q = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                sv = make_float4((q[0] + r1.x) + (r2.x + r3.x), (q[1] + r1.y) + (r2.y + r3.y),
+                                 (q[2] + r1.z) + (r2.z + r3.z), (q[3] + r1.w) + (r2.w + r3.w));
+            }
+            float4 o;
+            if (!act) {
+                o.x = fminf(fmaxf(pre4.x + sv.x, 0.f), hi);
+                o.y = fminf(fmaxf(pre4.y + sv.y, 0.f), hi);
+                o.z = fminf(fmaxf(pre4.z + sv.z, 0.f), hi);
+                o.w = fminf(fmaxf(pre4.w + sv.w, 0.f), hi);
+            } else {
+                o.x = (act4.x > 0.f && act4.x < hi) ? pre4.x + sv.x : 0.f;
+                o.y = (act4.y > 0.f && act4.y < hi) ? pre4.y + sv.y : 0.f;
+                o.z = (act4.z > 0.f && act4.z < hi) ? pre4.z + sv.z : 0.f;
+                o.w = (act4.w > 0.f && act4.w < hi) ? pre4.w + sv.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(out + orow * ld + row0 + 4 * kq) = o;
+            const u32x4 ou = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(ou, xrsrc, (unsigned)(row0 + 4 * kq) * 4u,
+                                                   (unsigned)(xb_cur + uj) * (unsigned)Hp * 4u, 16 /* sc1 */);
+        }
+        // the next step's staging overwrites the state rows in LDS: every wave must be done reading
+        __syncthreads();
+    }
+}
+
 size_t recurrent_xbuf_floats(int Hp, int64_t max_xrows)
 {
     return (size_t)2 * (size_t)max_xrows * Hp;  // one chunk-major state copy per direction
@@ -778,6 +938,25 @@ int launch_recurrent(const RecArgs& a, hipStream_t stream)
             SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL(sk, dim3(2 * nwg), dim3(256), smem, stream, a);
+            SCTC_HIP_TRY(hipGetLastError());
+            return SCTC_OK;
+        }
+    }
+    if (a.B > 5 && a.B <= 16 && a.variant != 1) {
+        RecKernel mk = nullptr;
+        switch ((nwg + 3) / 4) {
+            case 8:  if (nwg == 32)  mk = brnn_recurrent_m_kernel<8>;  break;   // H = 512
+            case 16: if (nwg == 64)  mk = brnn_recurrent_m_kernel<16>; break;   // H = 1024
+            case 29: if (nwg == 114) mk = brnn_recurrent_m_kernel<29>; break;   // H = 1824
+            case 32: if (nwg == 128) mk = brnn_recurrent_m_kernel<32>; break;   // H = 2048
+            default: break;
+        }
+        const size_t smem = sizeof(float) * ((size_t)16 * (a.Hp + 4) + 3 * 256);
+        if (mk && smem <= 160 * 1024) {
+            SCTC_HIP_TRY(hipMemsetAsync(a.xbuf, 0xFF, (size_t)2 * a.n_xrows * a.Hp * sizeof(float), stream));
+            SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mk),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(mk, dim3(2 * nwg), dim3(256), smem, stream, a);
             SCTC_HIP_TRY(hipGetLastError());
             return SCTC_OK;
         }

@@ -416,3 +416,36 @@ def test_recurrent_small_batch_kernel_layer_sizes(mods, monkeypatch, H):
     with np.errstate(all="ignore"):
         c_ref, _, _, _ = obrnn.cost_and_grad(params, datas[1], labs[1], TL, 20.0)
     assert costs[1] == pytest.approx(c_ref, rel=1e-4)
+
+
+@pytest.mark.parametrize("H,B", [(512, 6), (512, 16), (1824, 9), (2048, 12), (1024, 7)])
+def test_recurrent_mid_batch_kernel(mods, monkeypatch, H, B):
+    """6..16 utterances run the sentinel-exchange MFMA kernel (brnn_recurrent_m_kernel): ragged
+    minibatch against the flag-based kernel (SCTC_REC_VARIANT=1) and, at H=512, the oracle"""
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(31 * H + B)
+    D, A, NL, TL = 32, 33, 2, 1
+    Ts = [int(t) for t in rs.randint(2, 30, size=B)]
+    Ts[0] = 30
+    Ts[-1] = 1
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 8)).astype(np.int32) for T in Ts]
+    net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
+    costs, _, skips = net.costAndGradBatch(datas, labs)
+    g_m = _all_grads(net, NL)
+    net.costAndGradBatch(datas, labs)
+    for a, b in zip(g_m, _all_grads(net, NL)):
+        np.testing.assert_array_equal(a, b)          # run-to-run reproducible
+    if H == 512:
+        with np.errstate(all="ignore"):
+            costs_ref, g_ref, skips_ref, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+        np.testing.assert_array_equal(skips, skips_ref)
+        np.testing.assert_allclose(costs[~skips_ref], costs_ref[~skips_ref], rtol=1e-4)
+        check_grads(net, g_ref, NL)
+    monkeypatch.setenv("SCTC_REC_VARIANT", "1")
+    net1 = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
+    costs1, _, _ = net1.costAndGradBatch(datas, labs)
+    np.testing.assert_allclose(costs[~skips], costs1[~skips], rtol=1e-5)
+    for a, b in zip(g_m, _all_grads(net1, NL)):
+        assert rel(a, b) < 1e-4
