@@ -449,3 +449,24 @@ def test_recurrent_mid_batch_kernel(mods, monkeypatch, H, B):
     np.testing.assert_allclose(costs[~skips], costs1[~skips], rtol=1e-5)
     for a, b in zip(g_m, _all_grads(net1, NL)):
         assert rel(a, b) < 1e-4
+
+
+@pytest.mark.parametrize("H,B", [(64, 40), (512, 48), (512, 70)])
+def test_recurrent_large_minibatch(mods, H, B):
+    """more than 32 utterances: several utterance tiles per wave in the one-workgroup-per-CU
+    recurrent kernel (NTW = 2 / 4), ragged, against the float64 oracle"""
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(5 * H + B)
+    D, A, NL, TL = 24, 33, 2, 1
+    Ts = [int(t) for t in rs.randint(1, 22, size=B)]
+    Ts[3] = 22
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 8)).astype(np.int32) for T in Ts]
+    with np.errstate(all="ignore"):
+        costs_ref, g_ref, skips_ref, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+    net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
+    costs, _, skips = net.costAndGradBatch(datas, labs)
+    np.testing.assert_array_equal(skips, skips_ref)
+    np.testing.assert_allclose(costs[~skips_ref], costs_ref[~skips_ref], rtol=1e-4)
+    check_grads(net, g_ref, NL)
