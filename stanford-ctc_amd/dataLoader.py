@@ -86,15 +86,33 @@ class DataLoader:
 
     def loadDataFileDict(self, filenum):
         """Like loadDataFile, but the frames are returned as a dict utterance-id ->
-        (imgsize, nframes) float32 matrix (a copy, so the shard buffer can be released)."""
+        (imgsize, nframes) float32 matrix."""
         data_mat, alis, keys, sizes = self.loadDataFile(filenum)
         if not self.load_data:
             return None, alis, keys, sizes
+        # One copy of the cropped shard, [frames][imgsize] C-order -- into page-locked memory when a
+        # GPU is present, so that NNet's host->device staging is a DMA straight out of this buffer
+        # -- and per-utterance (imgsize, nframes) Fortran-ordered VIEWS into it (each view keeps the
+        # buffer alive).
+        frames = data_mat.shape[1]
+        shard = _host_buffer(frames, data_mat.shape[0])
+        shard[:] = data_mat.T
         data_dict = {}
         start = 0
         for k, s in zip(keys, sizes):
             end = start + int(s)
-            data_dict[k] = np.copy(data_mat[:, start:end])
+            data_dict[k] = shard[start:end].T
             start = end
-        assert start == data_mat.shape[1], "key file and feature file disagree on the frame count"
+        assert start == frames, "key file and feature file disagree on the frame count"
         return data_dict, alis, keys, sizes
+
+
+def _host_buffer(rows, cols):
+    """float32 [rows][cols]; pinned (page-locked) when torch sees a GPU, plain NumPy otherwise"""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.empty((rows, cols), dtype=torch.float32).pin_memory().numpy()
+    except Exception:
+        pass
+    return np.empty((rows, cols), dtype=np.float32)

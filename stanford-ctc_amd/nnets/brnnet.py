@@ -158,9 +158,20 @@ class NNet:
             d = np.asarray(d)
             if d.ndim != 2 or d.shape[0] != self.inputDim:
                 raise ValueError("data must be (inputDim, T); got %s" % (d.shape,))
+            # the loader's (inputDim, T) Fortran-ordered float32 views are [T][inputDim] in memory:
+            # no host copy; anything else is converted once
             rows.append(np.ascontiguousarray(d.T, dtype=np.float32))
-        host = rows[0] if len(rows) == 1 else np.concatenate(rows, axis=0)
-        return torch.from_numpy(host).cuda()
+        if len(rows) == 1:
+            return torch.from_numpy(rows[0]).cuda(non_blocking=True)
+        # one device block, one copy per utterance straight from where the features live
+        # (a DMA when that is the loader's page-locked shard buffer) -- no 60 MB host concatenate
+        dev = torch.empty((sum(r.shape[0] for r in rows), self.inputDim), dtype=torch.float32,
+                          device="cuda")
+        o = 0
+        for r in rows:
+            dev[o:o + r.shape[0]].copy_(torch.from_numpy(r), non_blocking=True)
+            o += r.shape[0]
+        return dev
 
     def _minibatch(self, feats_dev, T_b, labels_list):
         T_arr = np.ascontiguousarray(T_b, dtype=np.int32)

@@ -212,6 +212,39 @@ def sec_mfmarate():
           "16x16x4 f32 %.1f TFLOP/s (%.2f ms)" % tuple(out[4:]))
 
 
+def sec_sgdloop():
+    """end-to-end SGD loop (sgd.SGD.run: host features -> H2D -> costAndGrad -> fused Nesterov step)
+    against the bare costAndGrad step times"""
+    import logging
+    import sgd
+    from nnets import brnnet
+    logging.getLogger().setLevel(logging.WARNING)
+    D, A, H, NL, TL, T, U = 483, 33, 1824, 5, 3, 1000, 100
+    rs = np.random.RandomState(3)
+    for (mb, n_utts) in ((32, 128), (1, 24)):
+        np.random.seed(0)
+        net = brnnet.NNet(D, A, H, NL, T + 1, temporalLayer=TL, maxUtts=max(1, mb))
+        net.initParams()
+        opt = sgd.SGD(net, T + 1, alpha=1e-5, momentum=0.95, minibatch=mb)
+        keys = ["u%03d" % i for i in range(n_utts)]
+        import dataLoader
+        shard = dataLoader._host_buffer(n_utts * T, D)      # what DataLoader.loadDataFileDict returns
+        shard[:] = rs.randn(n_utts * T, D)
+        data = {k: shard[i * T:(i + 1) * T].T for i, k in enumerate(keys)}
+        alis = {k: rs.randint(1, A, size=U).astype(np.int32) for k in keys}
+        warm = keys[:max(mb, 4)]
+        opt.run(data, alis, list(warm))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        opt.run(data, alis, list(keys))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        steps = n_utts // max(1, mb)
+        print("sgd loop minibatch=%d: %d utterances in %.1f ms -> %.0f frames/s, %.2f ms per step" %
+              (mb, n_utts, dt * 1e3, n_utts * T / dt, dt / steps * 1e3))
+        del opt, net
+
+
 def sec_gemmstamp():
     """per-K-tile timeline of one GEMM block (needs a library built with -DSCTC_GEMM_STAMP)"""
     L = _sctc.lib()
@@ -340,7 +373,7 @@ def sec_recdbg(sync=0, B=32):
 
 def main():
     want = sys.argv[1:] or ["info", "gemm", "ctc", "brnn"]
-    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "gemmstamp": sec_gemmstamp, "gemmk": sec_gemmk, "twostream": sec_twostream, "fabric": sec_fabric, "mfmarate": sec_mfmarate, "ctc": sec_ctc,
+    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "gemmstamp": sec_gemmstamp, "gemmk": sec_gemmk, "twostream": sec_twostream, "fabric": sec_fabric, "sgdloop": sec_sgdloop, "mfmarate": sec_mfmarate, "ctc": sec_ctc,
              "brnn": lambda: sec_brnn("cfg3", 32, 0),
              "brnn1": lambda: sec_brnn("cfg3", 32, 1),
              "recdbg": lambda: sec_recdbg(0), "recdbg1": lambda: sec_recdbg(1), "recdbgB1": lambda: sec_recdbg(1, 1),
