@@ -44,6 +44,14 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 static constexpr unsigned long long SPIN_TIMEOUT_TICKS = 300000000ull;  // 3 s of the 100 MHz clock
 
+// s_sleep units (64 cycles) a consumer waits before its FIRST poll of a step.  A poll is a fabric
+// round trip (~1 us); one issued the moment the own results are published is almost always too
+// early and delays the next one by that round trip.  Measured: 5 units = -16 % per step for one
+// utterance (sentinel kernel), -3 % for the flag kernels at 32.
+#ifndef SCTC_POLL_DELAY
+#define SCTC_POLL_DELAY 5
+#endif
+
 __device__ __forceinline__ float4 ld_x(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off,
                                        unsigned chunk_off)
 {
@@ -84,6 +92,7 @@ __device__ __forceinline__ void wait_all(unsigned* flags, int nwg, unsigned targ
         const int lane = threadIdx.x;
         const unsigned long long t0 = wall_clock64();
         unsigned spins = 0;
+        __builtin_amdgcn_s_sleep(SCTC_POLL_DELAY);
         for (;;) {
             unsigned f0 = target, f1 = target;
             if (lane < nwg)
@@ -617,6 +626,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
         if (j > 0) {
             float* xcur = xs + (size_t)(j & 1) * SB * Hp;
             // ---- wave b fetches utterance b's previous state row: re-read until complete
+            __builtin_amdgcn_s_sleep(SCTC_POLL_DELAY);
             for (int bb = wave; bb < nb; bb += 4) {   // 4 waves, up to SB rows
                 const unsigned rowoff = (unsigned)(xb_prev + bb) * (unsigned)Hp * 4u;
                 u32x4 v[NQ];
@@ -790,6 +800,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_m_kernel(RecArgs p)
         for (int q = 0; q < 4; ++q) acc[q] = {0.f, 0.f, 0.f, 0.f};
         if (j > 0) {
             // ---- stage the previous state: rows round-robin over the waves, re-read until complete
+            __builtin_amdgcn_s_sleep(SCTC_POLL_DELAY);
             for (int bb = wave; bb < nb; bb += 4) {
                 const unsigned rowoff = (unsigned)(xb_prev + bb) * (unsigned)Hp * 4u;
                 const unsigned long long t0 = wall_clock64();
