@@ -29,17 +29,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SCTC_GEMM_OCC
 #define SCTC_GEMM_OCC 3
 #endif
-static constexpr int BM = 128, BK = SCTC_GEMM_BK, NTHREADS = 256;
+static constexpr int BK = SCTC_GEMM_BK;
 static constexpr int KQ = BK / 4;   // float4 per row of a K-contiguous operand tile
-// Block tile shapes.  128x128 (2x2 waves of 64x64) is the default; 128x96 (4x1 waves of
-// 32x96) serves column counts that 128 tiles badly: H = 1824 = 19 x 96 = 14.25 x 128.
-template <int BN_> struct TileCfg;
-template <> struct TileCfg<128> { static constexpr int WGM = 2, WGN = 2, OCC = SCTC_GEMM_OCC; };
-template <> struct TileCfg<96>  { static constexpr int WGM = 4, WGN = 1, OCC = 4; };
+// Block tile shapes (every wave owns TM x TN MFMA tiles of 32x32):
+//   0: 128x128, 2x2 waves of 64x64, 256 threads -- the default;
+//   1: 128x96,  4x1 waves of 32x96, 256 threads -- column counts that 128 tiles badly
+//      (H = 1824 = 19 x 96 = 14.25 x 128);
+// (96x96 with three waves was measured too: no quantisation loss on the H x H weight gradients,
+// but 105.9 instead of 110.6 TFLOP/s -- smaller tiles, three-wave blocks.)
+template <int SHAPE> struct TileCfg;
+template <> struct TileCfg<0> { static constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2, NT = 256, OCC = SCTC_GEMM_OCC; };
+template <> struct TileCfg<1> { static constexpr int BM = 128, BN = 96, WGM = 4, WGN = 1, NT = 256, OCC = 4; };
+static constexpr int N_SHAPES = 2;
 // LDS row strides (floats): transposed (K-contiguous) operands get rows + 1 (conflict-free
 // scalar writes), row-contiguous operands rows + 4 (ds_write_b128)
 __host__ __device__ constexpr int lds_stride(bool kcontig, int rows) { return kcontig ? rows + 1 : rows + 4; }
-__host__ __device__ constexpr int lds_floats(int bn) { return 2 * BK * (BM + 4) + 2 * BK * (bn + 4); }
+__host__ __device__ constexpr int lds_floats(int bm, int bn) { return 2 * BK * (bm + 4) + 2 * BK * (bn + 4); }
 
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& p, float v, int row, int col)
 {
@@ -51,11 +56,12 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& p, float v, int r
     return v;
 }
 
-template <bool AK, bool BKC, int BN_>
-__global__ __launch_bounds__(NTHREADS, TileCfg<BN_>::OCC) void gemm_f32_kernel(GemmArgs p)
+template <bool AK, bool BKC, int SHAPE>
+__global__ __launch_bounds__(TileCfg<SHAPE>::NT, TileCfg<SHAPE>::OCC) void gemm_f32_kernel(GemmArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int WGM = TileCfg<BN_>::WGM, WGN = TileCfg<BN_>::WGN;
+    constexpr int BM = TileCfg<SHAPE>::BM, BN_ = TileCfg<SHAPE>::BN, NTHREADS = TileCfg<SHAPE>::NT;
+    constexpr int WGM = TileCfg<SHAPE>::WGM, WGN = TileCfg<SHAPE>::WGN;
     constexpr int TM = BM / (WGM * 32), TN = BN_ / (WGN * 32);   // 32x32 MFMA tiles per wave
     constexpr int LDA = lds_stride(AK, BM), LDB = lds_stride(BKC, BN_);
     constexpr int OPA = BK * (BM + 4), OPB = BK * (BN_ + 4);     // floats per operand per buffer
@@ -362,24 +368,38 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p)
     }
 }
 
-// 96-column tiles when they waste at least 2 % fewer padded columns than 128-column tiles
-int gemm_pick_bn(int N)
+struct ShapeInfo { int bm, bn, occ; double penalty; };
+static const ShapeInfo kShapes[N_SHAPES] = {
+    {TileCfg<0>::BM, TileCfg<0>::BN, TileCfg<0>::OCC, 0.00},
+    {TileCfg<1>::BM, TileCfg<1>::BN, TileCfg<1>::OCC, 0.02},   // smaller tiles must save at least this much padded work
+};
+
+// tile shape with the least padded (wasted) matrix-core work for an M x N output
+int gemm_pick_shape(int M, int N)
 {
-    const double w128 = (double)((N + 127) / 128 * 128) / N, w96 = (double)((N + 95) / 96 * 96) / N;
-    return w96 + 0.02 < w128 ? 96 : 128;
+    const char* force = getenv("SCTC_GEMM_SHAPE");   // diagnostics: 0 / 1
+    if (force) return std::max(0, std::min(N_SHAPES - 1, atoi(force)));
+    int best = 0;
+    double best_cost = 1e30;
+    for (int i = 0; i < N_SHAPES; ++i) {
+        const double pm = (double)((M + kShapes[i].bm - 1) / kShapes[i].bm * kShapes[i].bm) / M;
+        const double pn = (double)((N + kShapes[i].bn - 1) / kShapes[i].bn * kShapes[i].bn) / N;
+        const double cost = pm * pn + kShapes[i].penalty;
+        if (cost < best_cost - 1e-12) { best_cost = cost; best = i; }
+    }
+    return best;
 }
 
 int64_t gemm_plan_splits(int M, int N, int K, int* splits)
 {
-    const int bn = gemm_pick_bn(N);
-    const int occ = bn == 96 ? TileCfg<96>::OCC : TileCfg<128>::OCC;
-    const int mt = (M + BM - 1) / BM, nt = (N + bn - 1) / bn;
+    const ShapeInfo& sh = kShapes[gemm_pick_shape(M, N)];
+    const int mt = (M + sh.bm - 1) / sh.bm, nt = (N + sh.bn - 1) / sh.bn;
     const int ktiles = (K + BK - 1) / BK;
     int s = 1;
     // 256 CUs x `occ` resident blocks.  A grid that is not a multiple of that leaves a partial
     // last round (225 tiles x 3 splits = 675 blocks ran at 66 %); pick the split that fills
     // whole rounds best, keeping >= 8 K tiles per split.
-    const int tiles = mt * nt, slots = 256 * occ;
+    const int tiles = mt * nt, slots = 256 * sh.occ;
     if (tiles < 2 * slots) {
         double best = 0.0;
         const int smax = std::min(64, std::max(1, ktiles / 8));
@@ -395,17 +415,18 @@ int64_t gemm_plan_splits(int M, int N, int K, int* splits)
     return s > 1 ? (int64_t)s * M * (N + 1) : 0;   // + [splits][M] column-sum partials
 }
 
-template <int BN_>
+template <int SHAPE>
 static int launch_tiles(GemmArgs a, hipStream_t stream)
 {
+    constexpr int BM = TileCfg<SHAPE>::BM, BN_ = TileCfg<SHAPE>::BN;
     const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN_ - 1) / BN_;
-    dim3 grid(mt * nt, a.splits), block(NTHREADS);
-    const size_t smem = sizeof(float) * lds_floats(BN_);  // 2 operands x 2 buffers
+    dim3 grid(mt * nt, a.splits), block(TileCfg<SHAPE>::NT);
+    const size_t smem = sizeof(float) * lds_floats(BM, BN_);  // 2 operands x 2 buffers
     void (*kern)(GemmArgs) = nullptr;
-    if (a.a_kcontig && a.b_kcontig) kern = gemm_f32_kernel<true, true, BN_>;
-    else if (a.a_kcontig && !a.b_kcontig) kern = gemm_f32_kernel<true, false, BN_>;
-    else if (!a.a_kcontig && a.b_kcontig) kern = gemm_f32_kernel<false, true, BN_>;
-    else kern = gemm_f32_kernel<false, false, BN_>;
+    if (a.a_kcontig && a.b_kcontig) kern = gemm_f32_kernel<true, true, SHAPE>;
+    else if (a.a_kcontig && !a.b_kcontig) kern = gemm_f32_kernel<true, false, SHAPE>;
+    else if (!a.a_kcontig && a.b_kcontig) kern = gemm_f32_kernel<false, true, SHAPE>;
+    else kern = gemm_f32_kernel<false, false, SHAPE>;
     static bool attr_set[4] = {false, false, false, false};
     const int vi = (a.a_kcontig ? 2 : 0) + (a.b_kcontig ? 1 : 0);
     if (!attr_set[vi]) {
@@ -431,9 +452,10 @@ int launch_gemm_f32(GemmArgs a, hipStream_t stream)
     else SCTC_CHECK_ARG(a.N % 4 == 0, "gemm: N must be a multiple of 4 (B row-contig)");
     if (a.splits < 1) a.splits = 1;
     if (a.splits > 1) SCTC_CHECK_ARG(a.splitk_ws != nullptr, "gemm: split-K without workspace");
-    const char* force = getenv("SCTC_GEMM_BN");   // diagnostics: 96 / 128
-    const int bn = force ? atoi(force) : gemm_pick_bn(a.N);
-    SCTC_TRY(bn == 96 ? launch_tiles<96>(a, stream) : launch_tiles<128>(a, stream));
+    switch (gemm_pick_shape(a.M, a.N)) {
+        case 1: SCTC_TRY(launch_tiles<1>(a, stream)); break;
+        default: SCTC_TRY(launch_tiles<0>(a, stream)); break;
+    }
     if (a.splits > 1) {
         const int64_t total = (int64_t)a.M * a.N;
         int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
