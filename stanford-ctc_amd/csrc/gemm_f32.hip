@@ -29,6 +29,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SCTC_GEMM_OCC
 #define SCTC_GEMM_OCC 3
 #endif
+#ifndef SCTC_GEMM_OCC1
+#define SCTC_GEMM_OCC1 4
+#endif
 static constexpr int BK = SCTC_GEMM_BK;
 static constexpr int KQ = BK / 4;   // float4 per row of a K-contiguous operand tile
 // Block tile shapes (every wave owns TM x TN MFMA tiles of 32x32):
@@ -39,7 +42,7 @@ static constexpr int KQ = BK / 4;   // float4 per row of a K-contiguous operand 
 // but 105.9 instead of 110.6 TFLOP/s -- smaller tiles, three-wave blocks.)
 template <int SHAPE> struct TileCfg;
 template <> struct TileCfg<0> { static constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2, NT = 256, OCC = SCTC_GEMM_OCC; };
-template <> struct TileCfg<1> { static constexpr int BM = 128, BN = 96, WGM = 4, WGN = 1, NT = 256, OCC = 4; };
+template <> struct TileCfg<1> { static constexpr int BM = 128, BN = 96, WGM = 4, WGN = 1, NT = 256, OCC = SCTC_GEMM_OCC1; };
 static constexpr int N_SHAPES = 2;
 // LDS row strides (floats): transposed (K-contiguous) operands get rows + 1 (conflict-free
 // scalar writes), row-contiguous operands rows + 4 (ds_write_b128)
