@@ -109,6 +109,12 @@ def lib():
             raise ImportError(
                 "libsctc_hip.so is missing (%s): build it with `python -c 'import "
                 "__graft_entry__ as g; g.build()'` -- there is no CPU fallback" % LIB_PATH)
+        # torch ships its own libamdhip64; load it FIRST so that this library binds to the same HIP
+        # runtime instance (two runtimes in one process: "no ROCm-capable device is detected")
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)          # AttributeError if the ABI is incomplete
