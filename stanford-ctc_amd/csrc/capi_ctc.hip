@@ -48,6 +48,10 @@ int ctc_make_plan(int B, int A, int blank, const int32_t* T_b, const int32_t* U_
     plan->blank = blank;
     plan->K = K;
     plan->W = W;
+    {
+        const char* lz = getenv("SCTC_CTC_LAZY");
+        plan->lazy = lz ? atoi(lz) : 0;
+    }
     plan->lp = 64 * W * K;
     plan->max_T = max_T;
     plan->lat_elems = frames * plan->lp;
@@ -123,7 +127,7 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
     la.beta = d_beta;
     la.ll = d_ll;
     la.skip2 = d_skip2;
-    SCTC_TRY(launch_ctc_lattice<R>(la, plan.B, plan.K, plan.W, stream));
+    SCTC_TRY(launch_ctc_lattice<R>(la, plan.B, plan.K, plan.W, sizeof(R) == 4 ? plan.lazy : 0, stream));
 
     CtcGradArgs<R> ga;
     ga.utts = d_utts;
@@ -141,6 +145,7 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
     ga.skip2 = d_skip2;
     ga.cost = cost;
     ga.skip = skip;
+    ga.lazy = sizeof(R) == 4 ? plan.lazy : 0;
     SCTC_TRY(launch_ctc_grad<R>(ga, plan.B, plan.max_T, stream));
     // the pageable host staging must outlive the async copies
     if (!keep) SCTC_HIP_TRY(hipStreamSynchronize(stream));

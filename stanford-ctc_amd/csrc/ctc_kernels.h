@@ -46,13 +46,14 @@ struct CtcGradArgs {
     const int32_t* skip2;
     double* cost;   // [B]
     int32_t* skip;  // [B]
+    int32_t lazy;   // lattices were produced with the every-4th-frame rescaling
 };
 
 // K states per lane and W waves per (utterance, pass) for rows of up to max_L states;
 // returns K (0 if 2U+1 > 2048), *waves = W; the lattice row stride is 64*W*K
 int ctc_lattice_shape(int max_L, int* waves);
 template <typename RI>
-int launch_ctc_lattice(const CtcLatticeArgs<RI>& a, int B, int K, int W, hipStream_t stream);
+int launch_ctc_lattice(const CtcLatticeArgs<RI>& a, int B, int K, int W, int lazy, hipStream_t stream);
 template <typename RI>
 int launch_ctc_grad(const CtcGradArgs<RI>& a, int B, int max_T, hipStream_t stream);
 int launch_softmax_rows(const float* x, float* y, int64_t rows, int A, int64_t ld,
@@ -64,6 +65,7 @@ int launch_argmax_rows(const void* y, int dtype, int32_t* best, int64_t rows, in
 // out in `ws`, uploads them and launches lattice + grad.
 struct CtcPlan {
     int B = 0, A = 0, blank = 0, K = 0, W = 1, lp = 0, max_T = 0;   // lp = 64*W*K
+    int lazy = 0;           // SCTC_CTC_LAZY=1: float32 probabilities rescale every 4th frame only
     int64_t lat_elems = 0;  // elements per lattice (alpha or beta)
     int64_t n_labels = 0;
     size_t bytes = 0;       // workspace bytes for this plan (float64 lattices)

@@ -146,13 +146,16 @@ __device__ __forceinline__ int64_t frame_row(const CtcUtt& u, const int32_t* row
 // RI: storage type of probs; the recursion itself runs in float64 (see ctc_kernels.h).
 //
 // Rescaling.  The reference divides every frame by its band sum c_t and accumulates
-// llForward = sum_t log c_t (ctc_fast.pyx:70-76); the per-frame scale cancels in the
-// gradient (:138-145).  Here a frame is rescaled only every RS-th step (RS = 4 for float32
-// probabilities, whose smallest value 1e-45 keeps four unscaled float64 steps above 1e-180;
-// RS = 1, the reference's schedule, for float64 probabilities): llForward is the log of the
-// last frame's mass minus the logs of the applied factors, the same number, while the
-// 64-lane reduction + division leave the per-step dependency chain.
-template <typename RI, int K, int NA, int W>
+// llForward = sum_t log c_t (ctc_fast.pyx:70-76); that schedule (RS = 1) is the default for both
+// probability types, so the lattices -- and with them the reference's underflow behaviour in
+// the gradient -- are reproduced exactly.  LAZY (SCTC_CTC_LAZY=1, float32 probabilities only)
+// rescales every 4th frame instead: the per-frame scale cancels in the gradient (:138-145),
+// float32's smallest value 1e-45 keeps four unscaled float64 steps above 1e-180, llForward is
+// the log of the last frame's mass minus the logs of the applied factors -- the same number --
+// and the 64-lane reduction + division leave most steps of the dependency chain (0.44 instead
+// of 0.7 ms at cfg-3).  It is numerically MORE robust than the reference (no underflow of the
+// forward-backward overlap), which is exactly why it is not the default: parity first.
+template <typename RI, int K, int NA, int W, bool LAZY>
 __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> p)
 {
     // W waves share one (utterance, pass): state s lives in global lane gl = s / K.  The two
@@ -163,11 +166,7 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
     using R = double;
     static_assert(K % 2 == 0 && K >= 2, "K must be even");
     constexpr int KH = K / 2;
-#ifdef SCTC_CTC_RS
-    constexpr int RS = SCTC_CTC_RS;
-#else
-    constexpr int RS = sizeof(RI) == 4 ? 4 : 1;
-#endif
+    constexpr int RS = LAZY ? 4 : 1;
     // Frames of probabilities prefetched per block.  gfx950 counts loads and stores in ONE
     // in-order counter (vmcnt), so waiting for a block's prefetch also waits for the lattice
     // rows stored before it: one HBM write latency per block.  Long blocks amortise it.
@@ -517,11 +516,31 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<RI> p)
     const R* al = p.alpha + u.lat_off + (int64_t)t * LP;
     const R* be = p.beta + u.lat_off + (int64_t)(T - 1 - t) * LP;  // stored reversed in t and s
     R* ab = ab_s + (size_t)wave * LP;
+    // Lazy schedule only (SCTC_CTC_LAZY=1): alpha and beta rows carry the lattice kernel's
+    // every-4th-frame scaling (a row can sit at 1e-180 for extremely peaked inputs), so both are
+    // brought to unit magnitude by an exact power of two before they are multiplied; the common
+    // factor cancels in g / (y * Z) (ctc_fast.pyx:141-145).  The default schedule normalises every
+    // frame like the reference and keeps its exact operation order -- including its underflow:
+    // where forward and backward normalisers have drifted apart by more than 1e308 the reference
+    // gets Z == 0 and returns grad = y for that frame, and so does this kernel.
+    int ea = 0, eb = 0;
+    if (p.lazy) {
+        R ma = (R)0, mb = (R)0;
+        for (int s = lane; s < L; s += 64) {
+            ma = fmax(ma, al[s]);
+            mb = fmax(mb, be[s]);
+        }
+        ma = wave_max(ma);
+        mb = wave_max(mb);
+        ea = ma > (R)0 ? -ilogb(ma) : 0;
+        eb = mb > (R)0 ? -ilogb(mb) : 0;
+    }
     R zpart = (R)0;
     for (int s = lane; s < L4; s += 64) {
         R v = (R)0;
         if (s < L) {
-            v = al[s] * be[L - 1 - s];                // :119
+            if (p.lazy) v = scalbn(al[s], ea) * scalbn(be[L - 1 - s], eb);
+            else v = al[s] * be[L - 1 - s];            // :119
             ab[s] = v;
             if (v != (R)0) v = v / (R)yr[lab_s[s]];    // :125-126 / :130-131
         } else {
@@ -556,12 +575,21 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<RI> p)
 // ---------------------------------------------------------------- launchers
 
 template <typename RI, int K, int W>
-static int launch_lattice_k(const CtcLatticeArgs<RI>& a, int B, int NA, hipStream_t stream)
+static int launch_lattice_k(const CtcLatticeArgs<RI>& a, int B, int NA, int lazy, hipStream_t stream)
 {
     dim3 grid(B, 2), block(64 * W);
-    if (NA == 1) hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 1, W>), grid, block, 0, stream, a);
-    else if (NA == 2) hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 2, W>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 4, W>), grid, block, 0, stream, a);
+    if constexpr (sizeof(RI) == 4) {
+        if (lazy) {
+            if (NA == 1) hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 1, W, true>), grid, block, 0, stream, a);
+            else if (NA == 2) hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 2, W, true>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 4, W, true>), grid, block, 0, stream, a);
+            SCTC_HIP_TRY(hipGetLastError());
+            return SCTC_OK;
+        }
+    }
+    if (NA == 1) hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 1, W, false>), grid, block, 0, stream, a);
+    else if (NA == 2) hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 2, W, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((ctc_lattice_kernel<RI, K, 4, W, false>), grid, block, 0, stream, a);
     SCTC_HIP_TRY(hipGetLastError());
     return SCTC_OK;
 }
@@ -586,23 +614,23 @@ int ctc_lattice_shape(int max_L, int* waves)
 }
 
 template <typename RI>
-int launch_ctc_lattice(const CtcLatticeArgs<RI>& a, int B, int K, int W, hipStream_t stream)
+int launch_ctc_lattice(const CtcLatticeArgs<RI>& a, int B, int K, int W, int lazy, hipStream_t stream)
 {
     using R = RI;
     const int NA = a.A <= 64 ? 1 : (a.A <= 128 ? 2 : 4);
     if (W == 4) {
         switch (K) {
-            case 2: return launch_lattice_k<R, 2, 4>(a, B, NA, stream);
-            case 4: return launch_lattice_k<R, 4, 4>(a, B, NA, stream);
-            case 8: return launch_lattice_k<R, 8, 4>(a, B, NA, stream);
+            case 2: return launch_lattice_k<R, 2, 4>(a, B, NA, lazy, stream);
+            case 4: return launch_lattice_k<R, 4, 4>(a, B, NA, lazy, stream);
+            case 8: return launch_lattice_k<R, 8, 4>(a, B, NA, lazy, stream);
         }
     } else {
         switch (K) {
-            case 2: return launch_lattice_k<R, 2, 1>(a, B, NA, stream);
-            case 4: return launch_lattice_k<R, 4, 1>(a, B, NA, stream);
-            case 8: return launch_lattice_k<R, 8, 1>(a, B, NA, stream);
-            case 16: return launch_lattice_k<R, 16, 1>(a, B, NA, stream);
-            case 32: return launch_lattice_k<R, 32, 1>(a, B, NA, stream);
+            case 2: return launch_lattice_k<R, 2, 1>(a, B, NA, lazy, stream);
+            case 4: return launch_lattice_k<R, 4, 1>(a, B, NA, lazy, stream);
+            case 8: return launch_lattice_k<R, 8, 1>(a, B, NA, lazy, stream);
+            case 16: return launch_lattice_k<R, 16, 1>(a, B, NA, lazy, stream);
+            case 32: return launch_lattice_k<R, 32, 1>(a, B, NA, lazy, stream);
         }
     }
     return set_error(SCTC_ERR_ARG, "ctc: label sequence too long (K=%d, W=%d)", K, W);
@@ -621,8 +649,8 @@ int launch_ctc_grad(const CtcGradArgs<R>& a, int B, int max_T, hipStream_t strea
     return SCTC_OK;
 }
 
-template int launch_ctc_lattice<float>(const CtcLatticeArgs<float>&, int, int, int, hipStream_t);
-template int launch_ctc_lattice<double>(const CtcLatticeArgs<double>&, int, int, int, hipStream_t);
+template int launch_ctc_lattice<float>(const CtcLatticeArgs<float>&, int, int, int, int, hipStream_t);
+template int launch_ctc_lattice<double>(const CtcLatticeArgs<double>&, int, int, int, int, hipStream_t);
 template int launch_ctc_grad<float>(const CtcGradArgs<float>&, int, int, hipStream_t);
 template int launch_ctc_grad<double>(const CtcGradArgs<double>&, int, int, hipStream_t);
 
