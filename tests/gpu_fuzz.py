@@ -43,13 +43,22 @@ def main():
         Ts = [int(t) for t in rs.randint(1, Tmax + 1, size=B)]
         Ts[int(rs.randint(B))] = Tmax
         params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+        reg = float(rs.choice([0.0, 0.0, 1e-3]))
+        max_act = float(rs.choice([20.0, 20.0, 3.0, 0.5]))
+        scale_w = float(rs.choice([1.0, 1.0, 0.05]))     # small weights: unsaturated units, gradients through every path
+        if scale_w != 1.0:
+            for key in ("W",):
+                params[key] = [w * scale_w for w in params[key]]
+            params["Wf"] = params["Wf"] * scale_w
+            params["Wb"] = params["Wb"] * scale_w
         datas = [rs.randn(D, T) for T in Ts]
         labs = [rs.randint(0, A, size=max(1, T // 6)).astype(np.int32) for T in Ts]
         def both(data_list):
             res = []
             for variant in ("0", "1"):
                 os.environ["SCTC_REC_VARIANT"] = variant
-                net = brnnet.NNet(D, A, H, NL, Tmax, temporalLayer=TL, maxUtts=B)
+                net = brnnet.NNet(D, A, H, NL, Tmax, temporalLayer=TL, maxUtts=B, reg=reg)
+                net.maxAct = max_act
                 net.setParams(host_stack(params))
                 costs, _, skips = net.costAndGradBatch(data_list, labs)
                 res.append((costs.copy(), skips.copy(), grads(net, NL)))
@@ -70,17 +79,19 @@ def main():
             datas = [d * (1.0 + 1e-5) for d in datas]
             note = " (boundary flip at %.1e, re-run perturbed)" % dg
             c0, s0, g0, dc, dg = both(datas)
-        msg = "case %2d H=%4d B=%2d NL=%d TL=%d A=%d Tmax=%2d skipped=%d: cost %.1e grad %.1e%s" % (
-            case, H, B, NL, TL, A, Tmax, int(s0.sum()), dc, dg, note)
+        msg = "case %2d H=%4d B=%2d NL=%d TL=%d A=%d Tmax=%2d reg=%g maxAct=%g w*%g skipped=%d: cost %.1e grad %.1e%s" % (
+            case, H, B, NL, TL, A, Tmax, reg, max_act, scale_w, int(s0.sum()), dc, dg, note)
         if H <= 512:
             with np.errstate(all="ignore"):
-                cr, gr, sr, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+                cr, gr, sr, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL, max_act=max_act, reg=reg)
             assert (sr == s0).all(), (case, "skip vs oracle")
             do = rel(g0[0], gr["W"][0])
             msg += " | vs oracle %.1e" % do
-            assert do < 2e-3, msg
+            # fp32 vs fp64 can put a unit on the other side of the clip boundary (more likely with a
+            # low ceiling); a handful of such flips moves the gradient by up to ~1e-2
+            assert do < (2e-3 if max_act >= 20.0 else 2e-2), msg
         print(msg, flush=True)
-        assert dc < 1e-5 and dg < 1e-4, msg
+        assert dc < 1e-5 and dg < (1e-4 if max_act >= 20.0 else 2e-2), msg
         worst = max(worst, dg)
     print("all %d cases agree (worst gradient difference %.1e)" % (n_cases, worst))
 
