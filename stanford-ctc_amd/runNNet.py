@@ -84,7 +84,10 @@ def run(args=None):
         output_dir = cfg["output_dir"]
     else:
         cfg = vars(opts).copy()
-        output_dir = opts.outputDir or os.path.join("runs", time.strftime("%Y%m%d_%H%M%S"))
+        stamp = time.strftime("%Y%m%d_%H%M%S")
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:      # every rank must arrive at the same directory
+            stamp = "dp_%s" % os.environ.get("MASTER_PORT", "0")
+        output_dir = opts.outputDir or os.path.join("runs", stamp)
         os.makedirs(output_dir, exist_ok=True)
         cfg["cfg_file"] = os.path.join(output_dir, "cfg.json")
     cfg["output_dir"] = output_dir
@@ -94,14 +97,32 @@ def run(args=None):
     cfg.setdefault("minibatch", 1)
     o = argparse.Namespace(**cfg)
 
-    logging.basicConfig(filename=os.path.join(output_dir, "test.log" if o.test else "train.log"),
+    # data-parallel extension: under `python -m torch.distributed.run --nproc-per-node N
+    # runNNet.py ... --minibatch M` every rank loads the same shards with the same seeds, processes
+    # its share of each minibatch and all-reduces the gradients (sgd.py / dist_sgd.py); rank 0 owns
+    # the run directory
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(os.environ.get("SCTC_DIST_BACKEND", "nccl"), rank=rank,
+                                    world_size=world)
+    master = rank == 0
+    o.master = master
+    logging.basicConfig(filename=os.path.join(output_dir, ("test.log" if o.test else "train.log") +
+                                              ("" if master else ".rank%d" % rank)),
                         level=logging.DEBUG, force=True)
     logger = logging.getLogger()
-    logger.addHandler(logging.StreamHandler())
+    if master:
+        logger.addHandler(logging.StreamHandler())
     logger.info("Running on %s" % o.host)
     np.random.seed(33)                     # runNNet.py:112-115
     random.seed(33)
-    cm.cuda_set_device(int(os.environ.get("CUDA_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    import torch
+    dev = int(os.environ.get("CUDA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    cm.cuda_set_device(dev % max(1, torch.cuda.device_count()))
     if o.test:
         return test(o, logger)
 
@@ -111,8 +132,9 @@ def run(args=None):
     nn.initParams()
     opt = sgd.SGD(nn, o.maxUttLen, alpha=o.step, momentum=o.momentum, minibatch=o.minibatch)
     cfg["param_count"] = int(nn._param_count)
-    with open(cfg["cfg_file"], "w") as f:
-        json.dump(cfg, f, indent=1, sort_keys=True)
+    if master:
+        with open(cfg["cfg_file"], "w") as f:
+            json.dump(cfg, f, indent=1, sort_keys=True)
 
     epoch_file = os.path.join(output_dir, "epoch")
     num_files_file = os.path.join(output_dir, "num_files")
@@ -129,7 +151,7 @@ def run(args=None):
         if k == start_epoch and os.path.exists(num_files_file):
             file_start = int(open(num_files_file).read().strip())
             logger.info("Starting from file %d, epoch %d" % (file_start, start_epoch))
-        else:
+        elif master:
             _write(num_files_file, str(file_start))
         if file_start < perm.shape[0]:
             loader.loadDataFileAsynch(int(perm[file_start]))
@@ -140,7 +162,7 @@ def run(args=None):
                 loader.loadDataFileAsynch(int(perm[i + 1]))      # prefetch
             opt.run(data_dict, alis, keys, sizes)
             logger.info("File time %f" % (time.time() - start))
-            if (i + 1) % o.save_every == 0:
+            if master and (i + 1) % o.save_every == 0:
                 logger.info("Saving parameters")
                 with open(o.out_file, "wb") as fid:
                     opt.toFile(fid)
@@ -149,15 +171,20 @@ def run(args=None):
                 if opt.expcost:
                     last = opt.expcost[-1] - (opt.regcost[-1] if (o.reg > 0.0 and opt.regcost) else 0.0)
                     _write(os.path.join(output_dir, "last_cost"), str(last))
-        _write(epoch_file, str(k))
-        # deliberate deviation: the reference leaves num_files at numFiles here, so a job resumed
-        # right after a completed epoch skips the whole next epoch (runNNet.py:163-169)
-        _write(num_files_file, "0")
-        with open(o.out_file + ".epoch{0:02}".format(k), "wb") as fid:
-            opt.toFile(fid)
-            nn.toFile(fid)
+        if master:
+            _write(epoch_file, str(k))
+            # deliberate deviation: the reference leaves num_files at numFiles here, so a job
+            # resumed right after a completed epoch skips the whole next epoch (runNNet.py:163-169)
+            _write(num_files_file, "0")
+            with open(o.out_file + ".epoch{0:02}".format(k), "wb") as fid:
+                opt.toFile(fid)
+                nn.toFile(fid)
         opt.alpha = opt.alpha / o.anneal
-    _write(os.path.join(output_dir, "sentinel"), "")   # run complete (run_utils.touch_file)
+    if master:
+        _write(os.path.join(output_dir, "sentinel"), "")   # run complete (run_utils.touch_file)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     return opt, nn
 
 

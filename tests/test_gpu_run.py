@@ -76,3 +76,49 @@ def test_train_resume_and_export(tmp_path):
         net.fromFile(f)
     p = net.costAndGrad(dd[keys[0]])
     np.testing.assert_allclose(np.log(p).T, ark[keys[0]], rtol=1e-5, atol=1e-6)
+
+
+def test_data_parallel_trainer_two_ranks(tmp_path):
+    """runNNet under torch.distributed.run with 2 ranks (gloo, both on the one GPU of the box):
+    every rank processes its share of each minibatch, gradients are all-reduced, rank 0 owns the
+    run directory -- and the parameters after one epoch equal those of the single-process run
+    with the same minibatch (mean over the same utterances; fp32 summation order aside)."""
+    import subprocess
+    import sys
+    import torch
+    assert torch.cuda.is_available()
+    import runNNet
+    rs = np.random.RandomState(1)
+    raw = img = 12
+    data = tmp_path / "data"
+    data.mkdir()
+    A = 6
+    utts = [("u%d" % i, int(rs.randint(12, 30)), list(rs.randint(1, A, size=3))) for i in range(8)]
+    write_shard(data, 1, utts, raw, rs)
+    common = ["--layerSize", "32", "--numLayers", "3", "--temporalLayer", "2", "--inputDim", str(img),
+              "--rawDim", str(raw), "--outputDim", str(A), "--maxUttLen", "40", "--numFiles", "1",
+              "--dataDir", str(data) + "/", "--step", "1e-3", "--momentum", "0.9", "--save_every", "1",
+              "--epochs", "1", "--minibatch", "4"]
+    single = tmp_path / "single"
+    runNNet.run(common + ["--outputDir", str(single)])
+    dp = tmp_path / "dp"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCTC_DIST_BACKEND="gloo", PYTHONPATH=os.pathsep.join(
+        [root, os.path.join(root, "stanford-ctc_amd"), os.environ.get("PYTHONPATH", "")]))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(root, "stanford-ctc_amd", "runNNet.py")] + common + ["--outputDir", str(dp)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert (dp / "sentinel").exists() and (dp / "train.log.rank1").exists()
+
+    def load(path):
+        with open(path, "rb") as f:
+            state = pickle.load(f)
+            return state, pickle.load(f)
+    (it_s, cost_s, _, _), stack_s = load(single / "params.pk")
+    (it_d, cost_d, _, _), stack_d = load(dp / "params.pk")
+    assert it_s == it_d == 2
+    np.testing.assert_allclose(cost_d, cost_s, rtol=1e-5)
+    for (ws, bs), (wd, bd) in zip(stack_s, stack_d):
+        np.testing.assert_allclose(wd, ws, rtol=2e-4, atol=1e-6)
