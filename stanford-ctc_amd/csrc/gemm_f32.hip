@@ -44,9 +44,14 @@ template <int SHAPE> struct TileCfg;
 template <> struct TileCfg<0> { static constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2, NT = 256, OCC = SCTC_GEMM_OCC; };
 template <> struct TileCfg<1> { static constexpr int BM = 128, BN = 96, WGM = 4, WGN = 1, NT = 256, OCC = SCTC_GEMM_OCC1; };
 static constexpr int N_SHAPES = 2;
-// LDS row strides (floats): transposed (K-contiguous) operands get rows + 1 (conflict-free
-// scalar writes), row-contiguous operands rows + 4 (ds_write_b128)
-__host__ __device__ constexpr int lds_stride(bool kcontig, int rows) { return kcontig ? rows + 1 : rows + 4; }
+// LDS row stride (floats): rows + 4 for both staging patterns.  Row-contiguous operands are
+// written with ds_write_b128; K-contiguous ones are transposed on the way in, lane (r = l/4,
+// c = l%4) writing element (k = 4c + j, row r): with a stride of 4 mod 16 the 64 lanes of one
+// k-row write hit 64 distinct banks.  (SQ_LDS_BANK_CONFLICT still reports 15-23 % of the
+// LDS-active cycles for these variants with this stride and with rows + 1 alike -- the compiler
+// pairs two k-rows into one ds_write2_b32, 128 dwords for 64 banks -- and the GEMM rate is the
+// same either way.)  Fragment reads are 32 consecutive floats per half-wave: conflict-free.
+__host__ __device__ constexpr int lds_stride(bool kcontig, int rows) { (void)kcontig; return rows + 4; }
 __host__ __device__ constexpr int lds_floats(int bm, int bn) { return 2 * BK * (bm + 4) + 2 * BK * (bn + 4); }
 
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& p, float v, int row, int col)
