@@ -74,6 +74,7 @@ struct sctc_brnn {
     int64_t N = 0;
     int B = 0, Tmax = 0;
     int64_t npairs = 0;
+    bool pairs_contig = false;
 
     // profiling
     int profiling = 0;
@@ -294,6 +295,11 @@ static int make_plan(sctc_brnn* h, const sctc_minibatch* mb, bool need_labels, h
             }
         }
     h->npairs = (int64_t)h->idx_hi.size();
+    // equal-length minibatches pair two CONTIGUOUS row ranges: then the recurrent weight gradient
+    // needs no row gather (plain pointers, 10 % faster GEMM)
+    h->pairs_contig = h->npairs > 0;
+    for (int64_t k = 1; k < h->npairs && h->pairs_contig; ++k)
+        h->pairs_contig = h->idx_hi[k] == h->idx_hi[0] + k && h->idx_lo[k] == h->idx_lo[0] + k;
     SCTC_HIP_TRY(hipMemcpyAsync(h->d_rowbase, h->rowbase.data(), sizeof(int32_t) * Tmax,
                                 hipMemcpyHostToDevice, stream));
     SCTC_HIP_TRY(hipMemcpyAsync(h->d_nact, h->nact.data(), sizeof(int32_t) * Tmax,
@@ -599,11 +605,17 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
                 g.A = k == 0 ? h->dF : h->dBk;
                 g.lda = LD(h->Hp);
                 g.a_kcontig = 0;
-                g.idx_a = k == 0 ? h->d_idx_hi : h->d_idx_lo;
                 g.B = k == 0 ? h->hF : h->hB;
                 g.ldb = LD(h->Hp);
                 g.b_kcontig = 0;
-                g.idx_b = k == 0 ? h->d_idx_lo : h->d_idx_hi;
+                if (h->pairs_contig) {
+                    const int64_t hi0 = h->idx_hi[0], lo0 = h->idx_lo[0];
+                    g.A += (k == 0 ? hi0 : lo0) * LD(h->Hp);
+                    g.B += (k == 0 ? lo0 : hi0) * LD(h->Hp);
+                } else {
+                    g.idx_a = k == 0 ? h->d_idx_hi : h->d_idx_lo;
+                    g.idx_b = k == 0 ? h->d_idx_lo : h->d_idx_hi;
+                }
                 g.M = h->Hp;
                 g.N = h->Hp;
                 g.K = (int)h->npairs;
