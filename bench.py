@@ -20,6 +20,10 @@ import time
 
 import numpy as np
 
+# the host driver only supports dmabuf IPC: RCCL (and any CUDA-tensor sharing across processes) needs
+# this before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "stanford-ctc_amd")):
     if p not in sys.path:

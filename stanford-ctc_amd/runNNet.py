@@ -27,7 +27,9 @@ import time
 
 import numpy as np
 
-import cudamat as cm
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only: RCCL needs it set early
+
+import cudamat as cm  # noqa: E402
 import dataLoader as dl
 import nnets.brnnet as rnnet
 import sgd
