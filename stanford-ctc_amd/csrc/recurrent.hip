@@ -52,6 +52,43 @@ static constexpr unsigned long long SPIN_TIMEOUT_TICKS = 300000000ull;  // 3 s o
 #define SCTC_POLL_DELAY 5
 #endif
 
+// Bounded spinning.  Called by a whole wave every few hundred polls: gives up when some
+// workgroup has already raised the error word or when this wait has lasted SPIN_TIMEOUT_TICKS,
+// in which case it raises the error word itself (the host turns it into SCTC_ERR_TIMEOUT).
+__device__ __forceinline__ bool spin_expired(unsigned* err, unsigned long long t0, int lane)
+{
+    bool give_up = false;
+    if (lane == 0) {
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            give_up = true;
+        else if (wall_clock64() - t0 > SPIN_TIMEOUT_TICKS) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            give_up = true;
+        }
+    }
+    return __any(give_up) != 0;
+}
+
+// One step's result for four consecutive units of one utterance (brnnet.py:146-152 forward:
+// clip(z + W h, 0, maxAct); :208-224 BPTT: (delta + W^T delta') masked by 0 < h < maxAct).
+__device__ __forceinline__ float4 step_result(const float4& pre, const float4& s, const float4& act,
+                                              bool bptt, float hi)
+{
+    float4 o;
+    if (!bptt) {
+        o.x = fminf(fmaxf(pre.x + s.x, 0.f), hi);
+        o.y = fminf(fmaxf(pre.y + s.y, 0.f), hi);
+        o.z = fminf(fmaxf(pre.z + s.z, 0.f), hi);
+        o.w = fminf(fmaxf(pre.w + s.w, 0.f), hi);
+    } else {
+        o.x = (act.x > 0.f && act.x < hi) ? pre.x + s.x : 0.f;
+        o.y = (act.y > 0.f && act.y < hi) ? pre.y + s.y : 0.f;
+        o.z = (act.z > 0.f && act.z < hi) ? pre.z + s.z : 0.f;
+        o.w = (act.w > 0.f && act.w < hi) ? pre.w + s.w : 0.f;
+    }
+    return o;
+}
+
 __device__ __forceinline__ float4 ld_x(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off,
                                        unsigned chunk_off)
 {
@@ -102,16 +139,7 @@ __device__ __forceinline__ void wait_all(unsigned* flags, int nwg, unsigned targ
             if (__all(f0 >= target && f1 >= target)) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 255u) == 0) {
-                bool give_up = false;
-                if (lane == 0) {
-                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-                        give_up = true;
-                    else if (wall_clock64() - t0 > SPIN_TIMEOUT_TICKS) {
-                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        give_up = true;
-                    }
-                }
-                if (__any(give_up)) break;
+                if (spin_expired(err, t0, lane)) break;
             }
         }
     }
@@ -308,20 +336,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
                     const f32x4 q = (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
                     s = make_float4(q[0] + r.x, q[1] + r.y, q[2] + r.z, q[3] + r.w);
                 }
-                float4 o;
-                if (!act) {
-                    // hFor[:,t] = clip(z[:,t] + Wf hFor[:,t-1], 0, maxAct)   brnnet.py:146-152
-                    o.x = fminf(fmaxf(pre4[i].x + s.x, 0.f), hi);
-                    o.y = fminf(fmaxf(pre4[i].y + s.y, 0.f), hi);
-                    o.z = fminf(fmaxf(pre4[i].z + s.z, 0.f), hi);
-                    o.w = fminf(fmaxf(pre4[i].w + s.w, 0.f), hi);
-                } else {
-                    // deltas[:,t] = (deltas[:,t] + W^T deltas[:,t+-1]) * [0 < h < maxAct]  brnnet.py:208-224
-                    o.x = (act4[i].x > 0.f && act4[i].x < hi) ? pre4[i].x + s.x : 0.f;
-                    o.y = (act4[i].y > 0.f && act4[i].y < hi) ? pre4[i].y + s.y : 0.f;
-                    o.z = (act4[i].z > 0.f && act4[i].z < hi) ? pre4[i].z + s.z : 0.f;
-                    o.w = (act4[i].w > 0.f && act4[i].w < hi) ? pre4[i].w + s.w : 0.f;
-                }
+                const float4 o = step_result(pre4[i], s, act4[i], act != nullptr, hi);
                 *reinterpret_cast<float4*>(out + orow[i] * ld + row0 + 4 * kq) = o;
                 st_x(xrsrc, xout[i], (unsigned)wg * chunk_stride, o, sync_mode);
             }
@@ -503,18 +518,7 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
                 s = make_float4((q[0] + r1.x) + (r2.x + r3.x), (q[1] + r1.y) + (r2.y + r3.y),
                                 (q[2] + r1.z) + (r2.z + r3.z), (q[3] + r1.w) + (r2.w + r3.w));
             }
-            float4 o;
-            if (!act) {
-                o.x = fminf(fmaxf(pre4.x + s.x, 0.f), hi);
-                o.y = fminf(fmaxf(pre4.y + s.y, 0.f), hi);
-                o.z = fminf(fmaxf(pre4.z + s.z, 0.f), hi);
-                o.w = fminf(fmaxf(pre4.w + s.w, 0.f), hi);
-            } else {
-                o.x = (act4.x > 0.f && act4.x < hi) ? pre4.x + s.x : 0.f;
-                o.y = (act4.y > 0.f && act4.y < hi) ? pre4.y + s.y : 0.f;
-                o.z = (act4.z > 0.f && act4.z < hi) ? pre4.z + s.z : 0.f;
-                o.w = (act4.w > 0.f && act4.w < hi) ? pre4.w + s.w : 0.f;
-            }
+            const float4 o = step_result(pre4, s, act4, act != nullptr, hi);
             *reinterpret_cast<float4*>(out + orow * ld + row0 + 4 * kq) = o;
             st_x(xrsrc, xout, (unsigned)wg * chunk_stride, o, sync_mode);
         }
@@ -644,16 +648,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
                         ok = ok && v[c][0] != XSENT && v[c][1] != XSENT && v[c][2] != XSENT && v[c][3] != XSENT;
                     if (__all(ok)) break;
                     if ((++spins & 255u) == 0) {
-                        bool give_up = false;
-                        if (lane == 0) {
-                            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-                                give_up = true;
-                            else if (wall_clock64() - t0 > SPIN_TIMEOUT_TICKS) {
-                                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                give_up = true;
-                            }
-                        }
-                        if (__any(give_up)) break;
+                        if (spin_expired(err, t0, lane)) break;
                     }
                 }
 #pragma unroll
@@ -818,16 +813,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_m_kernel(RecArgs p)
                         ok = ok && v[c][0] != XSENT && v[c][1] != XSENT && v[c][2] != XSENT && v[c][3] != XSENT;
                     if (__all(ok)) break;
                     if ((++spins & 255u) == 0) {
-                        bool give_up = false;
-                        if (lane == 0) {
-                            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-                                give_up = true;
-                            else if (wall_clock64() - t0 > SPIN_TIMEOUT_TICKS) {
-                                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                give_up = true;
-                            }
-                        }
-                        if (__any(give_up)) break;
+                        if (spin_expired(err, t0, lane)) break;
                     }
                 }
 #pragma unroll
@@ -861,18 +847,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_m_kernel(RecArgs p)
                 sv = make_float4((q[0] + r1.x) + (r2.x + r3.x), (q[1] + r1.y) + (r2.y + r3.y),
                                  (q[2] + r1.z) + (r2.z + r3.z), (q[3] + r1.w) + (r2.w + r3.w));
             }
-            float4 o;
-            if (!act) {
-                o.x = fminf(fmaxf(pre4.x + sv.x, 0.f), hi);
-                o.y = fminf(fmaxf(pre4.y + sv.y, 0.f), hi);
-                o.z = fminf(fmaxf(pre4.z + sv.z, 0.f), hi);
-                o.w = fminf(fmaxf(pre4.w + sv.w, 0.f), hi);
-            } else {
-                o.x = (act4.x > 0.f && act4.x < hi) ? pre4.x + sv.x : 0.f;
-                o.y = (act4.y > 0.f && act4.y < hi) ? pre4.y + sv.y : 0.f;
-                o.z = (act4.z > 0.f && act4.z < hi) ? pre4.z + sv.z : 0.f;
-                o.w = (act4.w > 0.f && act4.w < hi) ? pre4.w + sv.w : 0.f;
-            }
+            const float4 o = step_result(pre4, sv, act4, act != nullptr, hi);
             *reinterpret_cast<float4*>(out + orow * ld + row0 + 4 * kq) = o;
             const u32x4 ou = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
             __builtin_amdgcn_raw_buffer_store_b128(ou, xrsrc, (unsigned)(row0 + 4 * kq) * 4u,
