@@ -177,7 +177,7 @@ def main():
                          "launches_per_step": n_gemm_launches,
                          "avg_launch_ms": gemm_ms / n_gemm_launches,
                          "algorithmic_tflop_per_step": gm.value / 1e12},
-            "roofline_recurrent": {"bound": "mfma", "kernel": "brnn_recurrent_kernel",
+            "roofline_recurrent": {"bound": "latency (matrix pipes idle while the step hand-off crosses the fabric)", "kernel": "brnn_recurrent_q_kernel (two launches per step)",
                                    "achieved": rc.value / (rec_ms * 1e-3) / 1e12,
                                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": rc.value / (rec_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
