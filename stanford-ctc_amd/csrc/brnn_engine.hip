@@ -82,6 +82,7 @@ struct sctc_brnn {
     bool ev_ready = false;
     float phase_ms[SCTC_N_PHASES];
     int rec_sync_mode = 0;
+    int rec_poll_delay = -1;   // env SCTC_REC_POLL_DELAY (s_sleep units before a step's first poll; default by layer size)
     int rec_variant = 0;   // env SCTC_REC_VARIANT: 1 forces the one-workgroup-per-CU recurrent kernel
     // host staging of the CTC descriptors (must outlive the async uploads)
     void* ctc_stage = nullptr;
@@ -429,6 +430,7 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
             r.counters = h->counters;
             r.sync_mode = h->rec_sync_mode;
             r.variant = h->rec_variant;
+            r.poll_delay = h->rec_poll_delay;
             r.debug = h->rec_debug_on ? h->rec_debug : nullptr;
             SCTC_TRY(launch_recurrent(r, s));
             pt.begin(SCTC_PHASE_OTHER);
@@ -594,6 +596,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             r.counters = h->counters;
             r.sync_mode = h->rec_sync_mode;
             r.variant = h->rec_variant;
+            r.poll_delay = h->rec_poll_delay;
             r.debug = h->rec_debug_on ? h->rec_debug + REC_DEBUG_WORDS : nullptr;
             SCTC_TRY(launch_recurrent(r, s));
             pt.begin(SCTC_PHASE_BWD_GEMM);
@@ -721,6 +724,8 @@ int sctc_brnn_create(const sctc_brnn_config* cfg, float* params_dev, float* grad
     h->rec_sync_mode = sm ? atoi(sm) : 1;
     const char* rv = getenv("SCTC_REC_VARIANT");
     h->rec_variant = rv ? atoi(rv) : 0;
+    const char* pd = getenv("SCTC_REC_POLL_DELAY");
+    h->rec_poll_delay = pd ? atoi(pd) : -1;
     const char* dbg = getenv("SCTC_REC_DEBUG");
     h->rec_debug_on = dbg ? atoi(dbg) : 0;
     *out = h;

@@ -36,6 +36,7 @@ struct RecArgs {
     unsigned* counters;     // [REC_COUNTER_WORDS]: error word at [2], per-producer step flags from [4]
     int32_t sync_mode;      // 0: plain exchange stores + agent-scope release fence before the flag
                             // 1: write-through (sc1) exchange stores, no fence
+    int32_t poll_delay;     // s_sleep units (64 cycles) before the first poll of a step; < 0: pick by layer size
     int32_t variant;        // 0: pick automatically; 1: force the one-workgroup-per-CU kernel;
                             // 2: two-chain kernel with the linear (not XCD-grouped) block map
     unsigned* debug;        // nullable: s_memtime stamps [2 wgs][16 steps][8] for steps 64..79

@@ -44,13 +44,16 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 static constexpr unsigned long long SPIN_TIMEOUT_TICKS = 300000000ull;  // 3 s of the 100 MHz clock
 
-// s_sleep units (64 cycles) a consumer waits before its FIRST poll of a step.  A poll is a fabric
-// round trip (~1 us); one issued the moment the own results are published is almost always too
-// early and delays the next one by that round trip.  Measured: 5 units = -16 % per step for one
-// utterance (sentinel kernel), -3 % for the flag kernels at 32.
-#ifndef SCTC_POLL_DELAY
-#define SCTC_POLL_DELAY 5
-#endif
+// s_sleep units (64 cycles) a consumer waits before its FIRST poll of a step (RecArgs.poll_delay).
+// A poll is a fabric round trip (~1 us); one issued the moment the own results are published is
+// almost always too early and delays the next one by that round trip.  Measured (sentinel kernel,
+// one utterance): 5 units = -16 % per step at H = 1824 and -3 % at H = 2048, but +8 % at H = 1024
+// (fewer producers, less skew): the launcher picks 5 above 1024 units, 0 below; the flag kernels
+// gain 3 % at 32 utterances with 5.
+__device__ __forceinline__ void first_poll_delay(int units)
+{
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(1);
+}
 
 // Bounded spinning.  Called by a whole wave every few hundred polls: gives up when some
 // workgroup has already raised the error word or when this wait has lasted SPIN_TIMEOUT_TICKS,
@@ -123,13 +126,14 @@ __device__ __forceinline__ void publish_step(unsigned* flag, unsigned value, int
 }
 
 // all threads call; returns once every one of the `nwg` producers has published >= target
-__device__ __forceinline__ void wait_all(unsigned* flags, int nwg, unsigned target, unsigned* err)
+__device__ __forceinline__ void wait_all(unsigned* flags, int nwg, unsigned target, unsigned* err,
+                                         int poll_delay)
 {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const unsigned long long t0 = wall_clock64();
         unsigned spins = 0;
-        __builtin_amdgcn_s_sleep(SCTC_POLL_DELAY);
+        first_poll_delay(poll_delay);
         for (;;) {
             unsigned f0 = target, f1 = target;
             if (lane < nwg)
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
         }
 
         if (j > 0) {
-            wait_all(flags, nwg, (unsigned)j, err);
+            wait_all(flags, nwg, (unsigned)j, err, p.poll_delay);
             stamp(j, 1);
             // All x loads of a batch are issued, unconditionally, before its first MFMA
             // (up to 64 float4 = 256 VGPRs per lane): one latency + streaming per step.
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
         }
 
         if (j > 0) {
-            wait_all(flags, nwg, (unsigned)j, err);
+            wait_all(flags, nwg, (unsigned)j, err, p.poll_delay);
             stamp(j, 1);
             float4 x[NCQ];
 #pragma unroll
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
         if (j > 0) {
             float* xcur = xs + (size_t)(j & 1) * SB * Hp;
             // ---- wave b fetches utterance b's previous state row: re-read until complete
-            __builtin_amdgcn_s_sleep(SCTC_POLL_DELAY);
+            first_poll_delay(p.poll_delay);
             for (int bb = wave; bb < nb; bb += 4) {   // 4 waves, up to SB rows
                 const unsigned rowoff = (unsigned)(xb_prev + bb) * (unsigned)Hp * 4u;
                 u32x4 v[NQ];
@@ -795,7 +799,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_m_kernel(RecArgs p)
         for (int q = 0; q < 4; ++q) acc[q] = {0.f, 0.f, 0.f, 0.f};
         if (j > 0) {
             // ---- stage the previous state: rows round-robin over the waves, re-read until complete
-            __builtin_amdgcn_s_sleep(SCTC_POLL_DELAY);
+            first_poll_delay(p.poll_delay);
             for (int bb = wave; bb < nb; bb += 4) {
                 const unsigned rowoff = (unsigned)(xb_prev + bb) * (unsigned)Hp * 4u;
                 const unsigned long long t0 = wall_clock64();
@@ -887,8 +891,10 @@ static RecKernel pick_kernel(int nch_half)
     }
 }
 
-int launch_recurrent(const RecArgs& a, hipStream_t stream)
+int launch_recurrent(const RecArgs& a_in, hipStream_t stream)
 {
+    RecArgs a = a_in;
+    if (a.poll_delay < 0) a.poll_delay = a.Hp > 1024 ? 5 : 0;
     char why[128];
     if (!recurrent_supported(a.Hp, a.B, why, sizeof(why)))
         return set_error(SCTC_ERR_ARG, "recurrent kernel: %s", why);
