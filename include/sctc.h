@@ -164,6 +164,10 @@ typedef struct sctc_minibatch {
                                    the backward pass; if every utterance is skipped, return
                                    with the gradients untouched (brnnet.py:185-186) */
 #define SCTC_FLAG_ACCUMULATE 2  /* add into grads instead of overwriting */
+#define SCTC_FLAG_NO_REG_GRAD 4 /* leave the L2 term reg*W (brnnet.py:197-198,244-247) out of the
+                                   gradients: minibatch / data-parallel callers add it ONCE, after
+                                   the all-reduce and the 1/n_valid scaling (sctc_sumsq_reg,
+                                   sctc_nesterov_step_reg) */
 
 /* NNet.costAndGrad(data, labels) (brnnet.py:117-249) for a minibatch: forward,
  * softmax + CTC, backward.  Gradients are SUMMED over utterances (and frames) into
@@ -227,6 +231,23 @@ int sctc_sumsq(const float* x_dev, int64_t n, double* out_dev, void* workspace_d
 int sctc_nesterov_step(float* w_dev, float* v_dev, const float* g_dev, int64_t n, float mom,
                        float alpha, float max_gnorm, float grad_scale, const double* sumsq_dev,
                        void* stream);
+
+/* Minibatch / data-parallel form of the two calls above with the L2 term applied exactly once:
+ * the effective gradient is  e = grad_scale * g + reg * w  (g = SUM of the data gradients over the
+ * minibatch, all-reduced over the ranks; grad_scale = 1/n_valid; brnnet.py:197-198 adds reg*W to
+ * each utterance's gradient, whose minibatch MEAN is this).
+ *   sctc_sumsq_reg:          *out_dev = sum e^2 (float64 accumulation, two deterministic stages)
+ *   sctc_nesterov_step_reg:  alph = alpha * min(1, maxGNorm / sqrt(*sumsq_dev));
+ *                            v = mom*v - alph*e ;  w += v                                   */
+/*   noreg_ranges_host: n_ranges (<= 32) element ranges [beg, end) of the flat buffers that carry
+ *                      NO L2 term -- the biases (brnnet.py:197-200 regularises w only)          */
+int sctc_sumsq_reg(const float* g_dev, const float* w_dev, float grad_scale, float reg, int64_t n,
+                   const int64_t* noreg_ranges_host, int32_t n_ranges, double* out_dev,
+                   void* workspace_dev, size_t workspace_bytes, void* stream);
+int sctc_nesterov_step_reg(float* w_dev, float* v_dev, const float* g_dev, int64_t n, float mom,
+                           float alpha, float max_gnorm, float grad_scale, float reg,
+                           const int64_t* noreg_ranges_host, int32_t n_ranges,
+                           const double* sumsq_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -89,10 +89,16 @@ PROTOTYPES = {
     "sctc_nesterov_step": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_float,
                                           ctypes.c_float, ctypes.c_float, ctypes.c_float, vp,
                                           vp]),
+    "sctc_sumsq_reg": (ctypes.c_int, [vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_int64,
+                                      c_i64p, ctypes.c_int32, vp, vp, ctypes.c_size_t, vp]),
+    "sctc_nesterov_step_reg": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_float,
+                                              ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                              ctypes.c_float, c_i64p, ctypes.c_int32, vp, vp]),
 }
 
 FLAG_SYNC_SKIP = 1
 FLAG_ACCUMULATE = 2
+FLAG_NO_REG_GRAD = 4
 
 _lib = None
 

@@ -512,7 +512,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
 {
     const int64_t N = h->N;
     const int acc = (flags & SCTC_FLAG_ACCUMULATE) ? 1 : 0;
-    const float reg = h->cfg.reg;
+    const float reg = (flags & SCTC_FLAG_NO_REG_GRAD) ? 0.f : h->cfg.reg;
     const float* d_in = h->dlogits;
     int d_in_ld = LD(h->Ap);
     float* bufs[2] = {h->dA, h->dBuf};

@@ -114,6 +114,60 @@ __global__ __launch_bounds__(256) void nesterov_kernel(float* __restrict__ w, fl
     }
 }
 
+// minibatch / data-parallel form: effective gradient e = grad_scale*g + reg*w (the L2 term once);
+// the bias ranges of the flat buffer carry no L2 term
+struct NoRegRanges {
+    int n;
+    int64_t beg[32], end[32];
+};
+__device__ __forceinline__ float reg_at(const NoRegRanges& r, int64_t i, float reg)
+{
+    bool in = false;
+    for (int k = 0; k < r.n; ++k) in = in || (i >= r.beg[k] && i < r.end[k]);
+    return in ? 0.f : reg;
+}
+
+__global__ __launch_bounds__(256) void sumsq_reg_partial_kernel(const float* __restrict__ g,
+                                                                const float* __restrict__ w,
+                                                                float grad_scale, float reg,
+                                                                NoRegRanges nr, int64_t n,
+                                                                double* __restrict__ partial)
+{
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = (double)(grad_scale * g[i] + reg_at(nr, i, reg) * w[i]);
+        s += v * v;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void nesterov_reg_kernel(float* __restrict__ w, float* __restrict__ v,
+                                                           const float* __restrict__ g, int64_t n,
+                                                           float mom, float alpha, float max_gnorm,
+                                                           float grad_scale, float reg,
+                                                           NoRegRanges nr,
+                                                           const double* __restrict__ sumsq)
+{
+    float alph = alpha;
+    if (sumsq) {
+        const double gnorm = sqrt(*sumsq);
+        if (gnorm > (double)max_gnorm) alph = (float)((double)alpha * ((double)max_gnorm / gnorm));
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float e = grad_scale * g[i] + reg_at(nr, i, reg) * w[i];
+        const float nv = mom * v[i] - alph * e;
+        v[i] = nv;
+        w[i] += nv;
+    }
+}
+
 static inline int grid_for(int64_t n)
 {
     int64_t b = (n + 255) / 256;
@@ -205,6 +259,48 @@ int sctc_nesterov_step(float* w_dev, float* v_dev, const float* g_dev, int64_t n
     if (n == 0) return SCTC_OK;
     hipLaunchKernelGGL(nesterov_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
                        w_dev, v_dev, g_dev, n, mom, alpha, max_gnorm, grad_scale, sumsq_dev);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+static int make_ranges(const int64_t* host, int32_t n, NoRegRanges* out)
+{
+    SCTC_CHECK_ARG(n >= 0 && n <= 32 && (n == 0 || host), "noreg ranges: 0..32 [beg,end) pairs");
+    out->n = n;
+    for (int k = 0; k < n; ++k) { out->beg[k] = host[2 * k]; out->end[k] = host[2 * k + 1]; }
+    return SCTC_OK;
+}
+
+int sctc_sumsq_reg(const float* g_dev, const float* w_dev, float grad_scale, float reg, int64_t n,
+                   const int64_t* noreg_ranges_host, int32_t n_ranges, double* out_dev,
+                   void* workspace_dev, size_t workspace_bytes, void* stream)
+{
+    SCTC_CHECK_ARG(g_dev && w_dev && out_dev && workspace_dev && n >= 0, "sumsq_reg: bad argument");
+    NoRegRanges nr;
+    SCTC_TRY(make_ranges(noreg_ranges_host, n_ranges, &nr));
+    if (workspace_bytes < sumsq_ws_bytes())
+        return set_error(SCTC_ERR_WORKSPACE, "sumsq_reg: workspace %zu < %zu bytes", workspace_bytes,
+                         sumsq_ws_bytes());
+    const int blocks = (int)std::min<int64_t>(SS_BLOCKS, std::max<int64_t>(1, (n + 255) / 256));
+    hipLaunchKernelGGL(sumsq_reg_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       g_dev, w_dev, grad_scale, reg, nr, n, (double*)workspace_dev);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)workspace_dev, blocks, out_dev);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+int sctc_nesterov_step_reg(float* w_dev, float* v_dev, const float* g_dev, int64_t n, float mom,
+                           float alpha, float max_gnorm, float grad_scale, float reg,
+                           const int64_t* noreg_ranges_host, int32_t n_ranges,
+                           const double* sumsq_dev, void* stream)
+{
+    SCTC_CHECK_ARG(w_dev && v_dev && g_dev && n >= 0, "nesterov_step_reg: bad argument");
+    if (n == 0) return SCTC_OK;
+    NoRegRanges nr;
+    SCTC_TRY(make_ranges(noreg_ranges_host, n_ranges, &nr));
+    hipLaunchKernelGGL(nesterov_reg_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                       w_dev, v_dev, g_dev, n, mom, alpha, max_gnorm, grad_scale, reg, nr, sumsq_dev);
     SCTC_HIP_TRY(hipGetLastError());
     return SCTC_OK;
 }

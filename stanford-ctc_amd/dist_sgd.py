@@ -64,16 +64,23 @@ class DataParallel(object):
         self.group = group
         self.n_valid = 0
         self.cost_sum = 0.0
+        self.regcost = 0.0
 
-    def allreduce_gradients(self, n_valid_local, cost_sum_local=0.0):
+    def allreduce_gradients(self, n_valid_local, cost_sum_local=0.0, regcost_local=None):
         """after net.costAndGradBatch on every rank: sums gradients, utterance counts and costs
-        over the ranks.  Returns grad_scale = 1/n_valid_global (0 if every utterance skipped)."""
+        over the ranks.  `regcost_local`: this rank's L2 cost if it evaluated the model this step
+        (None for a rank whose shard was empty); self.regcost becomes the value of the ranks
+        that did (identical weights, so identical values).  Returns grad_scale =
+        1/n_valid_global (0 if every utterance skipped)."""
         import torch
         flat = self.net.grad.flat
-        side = torch.tensor([float(n_valid_local), float(cost_sum_local)], dtype=torch.float64,
+        side = torch.tensor([float(n_valid_local), float(cost_sum_local),
+                             0.0 if regcost_local is None else float(regcost_local),
+                             0.0 if regcost_local is None else 1.0], dtype=torch.float64,
                             device=flat.device)
         allreduce_flat(flat, side, self.bucket_elems, self.group)
         side = side.cpu()
         self.n_valid = int(round(side[0].item()))
         self.cost_sum = float(side[1].item())
+        self.regcost = float(side[2].item() / side[3].item()) if side[3].item() > 0 else 0.0
         return 1.0 / self.n_valid if self.n_valid > 0 else 0.0

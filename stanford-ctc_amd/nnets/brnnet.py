@@ -188,10 +188,14 @@ class NNet:
         return mb, keep
 
     def costAndGradBatch(self, data_list, labels_list, sync_skip=False, accumulate=False,
-                         feats_dev=None, T_b=None):
+                         feats_dev=None, T_b=None, reg_in_grad=True):
         """Minibatch step.  Returns (costs float64[B], grad stack, skips bool[B]); the
         gradient is the SUM over the non-skipped utterances.  `feats_dev`/`T_b` let the
-        caller pass features that already sit in HBM ([sum T][inputDim] float32)."""
+        caller pass features that already sit in HBM ([sum T][inputDim] float32).
+        With reg > 0 the L2 term reg*W is added once per CALL (brnnet.py:197-198 adds it
+        once per utterance = per call); minibatch / data-parallel trainers pass
+        reg_in_grad=False and apply it once after the all-reduce and the 1/n_valid scaling
+        (sgd.py here).  The costs never contain the L2 cost; self.regcost holds it."""
         if self._h is None:
             raise RuntimeError("initParams() / fromFile() first")
         if feats_dev is None:
@@ -205,7 +209,8 @@ class NNet:
         skip = np.zeros(B, dtype=np.int32)
         regcost = ctypes.c_double(0.0)
         flags = (_sctc.FLAG_SYNC_SKIP if sync_skip else 0) | \
-                (_sctc.FLAG_ACCUMULATE if accumulate else 0)
+                (_sctc.FLAG_ACCUMULATE if accumulate else 0) | \
+                (0 if reg_in_grad else _sctc.FLAG_NO_REG_GRAD)
         rc = _sctc.lib().sctc_brnn_cost_and_grad(
             self._h, ctypes.byref(mb), flags, cost.ctypes.data_as(_sctc.c_f64p),
             skip.ctypes.data_as(_sctc.c_i32p), ctypes.byref(regcost), _sctc.current_stream_ptr())
@@ -275,8 +280,18 @@ class NNet:
             stack.append([w.numpy_array, b.numpy_array])
         pickle.dump(stack, fid)
 
+    def noreg_ranges(self):
+        """[beg, end) element ranges of the flat parameter buffer that hold biases (no L2 term)"""
+        r = []
+        for ti in self._infos:
+            if ti.kind == 1:
+                r += [int(ti.offset), int(ti.offset) + cm.padded_layout(ti.rows, ti.cols)[0]]
+        return np.ascontiguousarray(r, dtype=np.int64)
+
     def fromFile(self, fid):
-        stack = pickle.load(fid)
+        # encoding='latin1': params.pk written by the reference is a Python-2 cPickle of NumPy
+        # arrays (brnnet.py:258-267), which Python 3 can only read this way
+        stack = pickle.load(fid, encoding='latin1')
         if self._h is None:
             self._allocate()
         for (w, b), (wi, bi) in zip(self.stack, stack):

@@ -69,12 +69,41 @@ def build_parser():
 
 
 def _write(path, text):
-    with open(path, "w") as f:
+    """small bookkeeping files are replaced atomically: a reader never sees an empty file"""
+    tmp = "%s.tmp%d" % (path, os.getpid())
+    with open(tmp, "w") as f:
         f.write(text)
+    os.replace(tmp, path)
+
+
+def _bcast(obj, world):
+    """rank 0's value on every rank (run directory, resume position)"""
+    if world <= 1:
+        return obj
+    import torch.distributed as dist
+    box = [obj]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
 
 
 def run(args=None):
     opts = build_parser().parse_args(args)
+    # data-parallel extension (SURVEY 8(e)): under `python -m torch.distributed.run --nproc-per-node N
+    # runNNet.py ... --minibatch M` every rank loads the same shards with the same seeds, processes
+    # its share of each minibatch and all-reduces the gradients (sgd.py / dist_sgd.py); rank 0 owns
+    # the run directory and the resume bookkeeping and broadcasts both
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            import torch
+            # the device must be chosen before the first (object) collective
+            dev = int(os.environ.get("CUDA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            torch.cuda.set_device(dev % max(1, torch.cuda.device_count()))
+            dist.init_process_group(os.environ.get("SCTC_DIST_BACKEND", "nccl"), rank=rank,
+                                    world_size=world)
     if opts.cfg_file:
         with open(opts.cfg_file) as f:
             cfg = json.load(f)
@@ -86,10 +115,9 @@ def run(args=None):
         output_dir = cfg["output_dir"]
     else:
         cfg = vars(opts).copy()
-        stamp = time.strftime("%Y%m%d_%H%M%S")
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1:      # every rank must arrive at the same directory
-            stamp = "dp_%s" % os.environ.get("MASTER_PORT", "0")
-        output_dir = opts.outputDir or os.path.join("runs", stamp)
+        # every rank must arrive at the same (fresh, timestamped) directory: rank 0 names it
+        output_dir = _bcast(opts.outputDir or os.path.join("runs", time.strftime("%Y%m%d_%H%M%S")),
+                            world)
         os.makedirs(output_dir, exist_ok=True)
         cfg["cfg_file"] = os.path.join(output_dir, "cfg.json")
     cfg["output_dir"] = output_dir
@@ -99,18 +127,6 @@ def run(args=None):
     cfg.setdefault("minibatch", 1)
     o = argparse.Namespace(**cfg)
 
-    # data-parallel extension: under `python -m torch.distributed.run --nproc-per-node N
-    # runNNet.py ... --minibatch M` every rank loads the same shards with the same seeds, processes
-    # its share of each minibatch and all-reduces the gradients (sgd.py / dist_sgd.py); rank 0 owns
-    # the run directory
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(os.environ.get("SCTC_DIST_BACKEND", "nccl"), rank=rank,
-                                    world_size=world)
     master = rank == 0
     o.master = master
     logging.basicConfig(filename=os.path.join(output_dir, ("test.log" if o.test else "train.log") +
@@ -140,8 +156,15 @@ def run(args=None):
 
     epoch_file = os.path.join(output_dir, "epoch")
     num_files_file = os.path.join(output_dir, "num_files")
-    start_epoch = int(open(epoch_file).read()) + 1 if os.path.exists(epoch_file) else 0
-    if os.path.exists(o.in_file):          # resume, runNNet.py:150-154
+    # only rank 0 reads the bookkeeping files (it is also their only writer)
+    start_epoch, resume_file, have_ckpt = 0, None, False
+    if master:
+        start_epoch = int(open(epoch_file).read()) + 1 if os.path.exists(epoch_file) else 0
+        if os.path.exists(num_files_file):
+            resume_file = int(open(num_files_file).read().strip())
+        have_ckpt = os.path.exists(o.in_file)
+    start_epoch, resume_file, have_ckpt = _bcast((start_epoch, resume_file, have_ckpt), world)
+    if have_ckpt:                          # resume, runNNet.py:150-154
         with open(o.in_file, "rb") as fid:
             opt.fromFile(fid)
             opt.alpha = opt.alpha / (o.anneal ** start_epoch)
@@ -150,8 +173,8 @@ def run(args=None):
     for k in range(start_epoch, o.epochs):
         perm = np.random.permutation(o.numFiles) + 1
         file_start = 0
-        if k == start_epoch and os.path.exists(num_files_file):
-            file_start = int(open(num_files_file).read().strip())
+        if k == start_epoch and resume_file is not None:
+            file_start = resume_file
             logger.info("Starting from file %d, epoch %d" % (file_start, start_epoch))
         elif master:
             _write(num_files_file, str(file_start))
@@ -192,7 +215,7 @@ def run(args=None):
 
 def test(o, logger):
     with open(o.in_file, "rb") as fid:
-        pickle.load(fid)                   # SGD data, not needed (runNNet.py:217-218)
+        pickle.load(fid, encoding="latin1")    # SGD data, not needed (runNNet.py:217-218); py2 pickles
         loader = dl.DataLoader(o.dataDir, o.rawDim, o.inputDim, o.alisDir or o.dataDir)
         nn = rnnet.NNet(o.inputDim, o.outputDim, o.layerSize, o.numLayers, o.maxUttLen,
                         temporalLayer=o.temporalLayer, train=False, maxUtts=16)

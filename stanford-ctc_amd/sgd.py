@@ -24,6 +24,8 @@ import numpy as np
 import _sctc
 import dist_sgd
 
+MAX_LATTICE_STATES = 2048      # 2U+1 limit of the CTC lattice kernels (csrc/capi_ctc.hip)
+
 
 class SGD:
 
@@ -64,7 +66,8 @@ class SGD:
         pickle.dump([self.it, self.costt, self.expcost, stack], fid)
 
     def fromFile(self, fid):
-        it, costt, expcost, stack = pickle.load(fid)
+        # latin1: the reference writes this with Python-2 cPickle (sgd.py:36-42)
+        it, costt, expcost, stack = pickle.load(fid, encoding='latin1')
         self.it = it
         self.costt = costt
         self.expcost = expcost
@@ -76,16 +79,34 @@ class SGD:
 
     # ------------------------------------------------------------------ device-side step
 
-    def _grad_sumsq(self):
+    def _grad_sumsq(self, grad_scale=1.0, reg=0.0):
+        """|| effective gradient ||^2 on the device.  reg == 0: sum g^2 (the caller scales the norm
+        by grad_scale); reg > 0 (minibatch / data-parallel): sum (grad_scale*g + reg*w)^2 with the
+        L2 term entering exactly once, after the all-reduce (biases excluded, brnnet.py:197-200)"""
         g = self.model.grad.flat
+        if reg > 0.0:
+            nr = self.model.noreg_ranges()
+            _sctc.check(_sctc.lib().sctc_sumsq_reg(
+                g.data_ptr(), self.model._params.data_ptr(), float(grad_scale), float(reg),
+                g.numel(), _sctc.i64(nr), len(nr) // 2, self._sumsq.data_ptr(),
+                self._ws.data_ptr(), self._ws.numel(), _sctc.current_stream_ptr()), "euclid_norm")
+            return
         _sctc.check(_sctc.lib().sctc_sumsq(g.data_ptr(), g.numel(), self._sumsq.data_ptr(),
                                            self._ws.data_ptr(), self._ws.numel(),
                                            _sctc.current_stream_ptr()), "euclid_norm")
 
-    def _apply(self, mom, grad_scale):
+    def _apply(self, mom, grad_scale, reg=0.0):
         """velocity = mom*velocity - alph*grad ; params += velocity  (sgd.py:129-141,161) with
         alph = alpha * min(1, maxGNorm/gnorm) evaluated on the device"""
         m = self.model
+        if reg > 0.0:
+            nr = m.noreg_ranges()
+            _sctc.check(_sctc.lib().sctc_nesterov_step_reg(
+                m._params.data_ptr(), self.velocity.flat.data_ptr(), m.grad.flat.data_ptr(),
+                m._params.numel(), float(mom), float(self.alpha), float(self.maxGNorm),
+                float(grad_scale), float(reg), _sctc.i64(nr), len(nr) // 2,
+                self._sumsq.data_ptr(), _sctc.current_stream_ptr()), "SGD step")
+            return
         _sctc.check(_sctc.lib().sctc_nesterov_step(
             m._params.data_ptr(), self.velocity.flat.data_ptr(), m.grad.flat.data_ptr(),
             m._params.numel(), float(mom), float(self.alpha), float(self.maxGNorm),
@@ -129,6 +150,14 @@ class SGD:
                 logging.info("SKIPPING utt frames less than label length (Utterance length %d, "
                              "Num Labels %d)." % (mb_data.shape[1], mb_labels.shape[0]))
                 continue
+            # conditions the engine rejects with ValueError (the reference would index out of
+            # bounds / has no lattice-width limit): one bad utterance must not end the run
+            if mb_labels.shape[0] < 1 or 2 * mb_labels.shape[0] + 1 > MAX_LATTICE_STATES or \
+                    mb_labels.min() < 0 or mb_labels.max() >= self.model.outputDim:
+                logging.info("SKIPPING utt with unusable labels (Num Labels %d, ids %s..%s)."
+                             % (mb_labels.shape[0], mb_labels.min() if mb_labels.size else '-',
+                                mb_labels.max() if mb_labels.size else '-'))
+                continue
             if self.minibatch <= 1:
                 self._step([(k, mb_data, mb_labels)], momIncrease, mom)
             else:
@@ -151,38 +180,52 @@ class SGD:
         else:
             local = batch
         m = self.model
+        # minibatch / data-parallel: the engine returns the SUM of the data gradients; the L2
+        # term enters once, after the all-reduce and the 1/n_valid scaling (_grad_sumsq/_apply)
+        reference_mode = len(batch) == 1 and world == 1
+        reg_late = 0.0 if reference_mode else float(m.reg)
         # w = w + mom*velocity (evaluate gradient at future point), sgd.py:91-93
         m.updateParams(mom, self.velocity)
-        if len(batch) == 1 and world == 1:
-            k, data, labels = batch[0]
-            cost, grad, skip = m.costAndGrad(data, labels)
-            costs, skips = np.array([cost]), np.array([skip])
-        elif local:
-            costs, grad, skips = m.costAndGradBatch([d for _, d, _ in local],
-                                                    [l for _, _, l in local])
-        else:
-            m.grad.flat.zero_()
-            costs, skips = np.zeros(0), np.zeros(0, dtype=bool)
-        # undo update: w = w - mom*velocity, sgd.py:97-100
-        m.updateParams(-mom, self.velocity)
+        try:
+            if reference_mode:
+                k, data, labels = batch[0]
+                cost, grad, skip = m.costAndGrad(data, labels)
+                if m.reg > 0:
+                    cost -= m.regcost        # bookkept below like the batched path
+                costs, skips = np.array([cost]), np.array([skip])
+            elif local:
+                costs, grad, skips = m.costAndGradBatch([d for _, d, _ in local],
+                                                        [l for _, _, l in local],
+                                                        reg_in_grad=False)
+            else:
+                m.grad.flat.zero_()
+                costs, skips = np.zeros(0), np.zeros(0, dtype=bool)
+        finally:
+            # undo update: w = w - mom*velocity, sgd.py:97-100 (also when the engine raised)
+            m.updateParams(-mom, self.velocity)
         n_valid = int((~skips).sum())
         cost_sum = float(np.sum(costs[~skips])) if n_valid else 0.0
         if world > 1:
             if n_valid == 0:
                 m.grad.flat.zero_()     # stale gradients must not enter the all-reduce
-            self._dp.allreduce_gradients(n_valid, cost_sum)
+            self._dp.allreduce_gradients(n_valid, cost_sum,
+                                         m.regcost if (local and m.reg > 0) else None)
             n_valid, cost_sum = self._dp.n_valid, self._dp.cost_sum
+            if m.reg > 0:
+                m.regcost = self._dp.regcost
         if n_valid == 0:
             for (k, d, l) in batch:
                 logging.info("SKIPPING: Key=%s, SeqLen=%d, NumFrames=%d." % (k, l.shape[0], d.shape[1]))
             return
         grad_scale = 1.0 / n_valid      # mean over non-skipped utterances (1.0 for the reference's B=1)
         # Compute norm of all parameters as one vector (sgd.py:102-107): one reduction
-        self._grad_sumsq()
-        cost = cost_sum / n_valid
+        self._grad_sumsq(grad_scale, reg_late)
+        # the reference's cost includes the L2 cost (brnnet.py:178-183); same convention for
+        # every minibatch size (rank-local regcost is identical on all ranks)
+        cost = cost_sum / n_valid + (m.regcost if m.reg > 0 else 0.0)
         self._bookkeep(cost)
-        self._apply(mom, grad_scale)
-        self.last_gnorm = float(np.sqrt(self._sumsq.item())) * grad_scale
+        self._apply(mom, grad_scale, reg_late)
+        self.last_gnorm = float(np.sqrt(self._sumsq.item())) * (1.0 if reg_late > 0 else grad_scale)
         if rank == 0:
             k, d, l = batch[0]
             logging.info("Iter %d : Cost=%.4f, ExpCost=%.4f, GradNorm=%.4f, SeqLen=%d, NumFrames=%d."
