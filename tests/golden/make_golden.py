@@ -17,7 +17,12 @@ Fixtures:
   ctc_skip.npz        G4     infeasible / zero-probability cases (skip=True) + feasible twins
   ctc_mid.npz         G8     T=1000/2000 A=33 randn->softmax (cost + strided grad slice)
   brnn_main.npz       G3     rnnetcpu.py __main__ (seed 33; D=20,H=30,NL=3,TL=2,A=6,T=10)
-  brnn_cfg.npz        G6     scaled-down cfg-1/2/3/5 shaped nets through rnnetcpu
+  brnn_cfg.npz        G6     scaled-down cfg-1/2/3/4/5 shaped nets through rnnetcpu
+  loader_ref.npz + shard/  output of the reference's dataLoader.py:38-95 (lib2to3-converted in
+                      scratch) on a small shard (feats1.bin / keys1.txt / alis1.txt, kept as data)
+  ref_py2_params.pk + ref_py2_params.npz   a params.pk in the byte format Python-2 cPickle
+                      (protocol 0, the reference's `pickle.dump(obj, fid)`) writes for
+                      sgd.py:36-42 + brnnet.py:258-267, emitted opcode by opcode (no Python 2 here)
 """
 import argparse
 import contextlib
@@ -55,6 +60,19 @@ def build_reference(scratch):
             subprocess.check_call(["expand", "-t", "8", src], stdout=f)
         subprocess.check_call([sys.executable, "-m", "lib2to3", "-w", "-n", twin],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    ldr = os.path.join(scratch, "dataLoader_e.py")
+    if not os.path.exists(ldr):
+        src = os.path.join(REF, "ctc_fast/dataLoader.py")
+        with open(ldr, "w") as f:
+            subprocess.check_call(["expand", "-t", "8", src], stdout=f)
+        subprocess.check_call([sys.executable, "-m", "lib2to3", "-w", "-n", ldr],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        # Python-2 `int / int` is floor division (dataLoader.py:63): the one semantic fix lib2to3
+        # does not make
+        txt = open(ldr).read()
+        assert "(self.rawsize-self.imgsize)/2" in txt
+        open(ldr, "w").write(txt.replace("(self.rawsize-self.imgsize)/2",
+                                         "(self.rawsize-self.imgsize)//2"))
     sys.path.insert(0, scratch)
     import ctc_fast  # noqa: the reference's Cython module (sets np.seterr raise at import)
     import rnnetcpu_e
@@ -168,7 +186,7 @@ def mid_input(T, A, U, seed):
 
 def gen_mid(cf):
     out = {}
-    for T, U in ((1000, 100), (2000, 200)):
+    for T, U in ((1000, 100), (2000, 200), (8000, 800)):
         logits, seq = mid_input(T, 33, U, 0)
         y = softmax0(logits)
         cost, grad, skip = ref_ctc(cf, y, seq)
@@ -176,7 +194,7 @@ def gen_mid(cf):
         k = "T%d" % T
         out[k + "_cost"] = np.float64(cost)
         out[k + "_sum_abs_grad"] = np.float64(np.abs(grad).sum())
-        out[k + "_grad_stride41"] = grad[:, ::41]
+        out[k + "_grad_stride41"] = grad[:, ::(41 if T <= 2000 else 163)]
         out[k + "_grad_rowsum"] = grad.sum(axis=1)
         out[k + "_logits_checksum"] = np.float64(logits.sum())
         out[k + "_seq"] = seq
@@ -233,8 +251,11 @@ def gen_brnn_cfg(tw):
     and the clipped GPU model coincide (asserted)."""
     out = {}
     shapes = {"cfg1": (16, 28, 24, 2, 1, 40, 6), "cfg2": (20, 62, 32, 3, 2, 48, 7),
-              "cfg3": (21, 33, 32, 5, 3, 40, 5), "cfg5": (16, 33, 24, 7, 4, 32, 4)}
-    for seed, (name, (D, A, H, NL, TL, T, U)) in enumerate(sorted(shapes.items())):
+              "cfg3": (21, 33, 32, 5, 3, 40, 5), "cfg5": (16, 33, 24, 7, 4, 32, 4),
+              "cfg4": (30, 33, 32, 5, 3, 64, 6)}
+    seeds = {"cfg1": 0, "cfg2": 1, "cfg3": 2, "cfg5": 3, "cfg4": 4}   # fixed: adding a twin moves no other
+    for name, (D, A, H, NL, TL, T, U) in sorted(shapes.items()):
+        seed = seeds[name]
         rs = np.random.RandomState(100 + seed)
         data = rs.randn(D, T)
         labels = rs.randint(1, A, size=U).astype(np.int32)
@@ -260,6 +281,196 @@ def gen_brnn_cfg(tw):
     np.savez(os.path.join(HERE, "brnn_cfg.npz"), **out)
 
 
+def gen_loader(scratch):
+    """ctc_fast/dataLoader.py:38-95 on a small shard: the shard files are kept (data in the
+    reference's own on-disk format: Kaldi export of util/swbd/write_feats.sh:71) together with
+    what the reference's loader returns for them."""
+    import dataLoader_e
+    rs = np.random.RandomState(11)
+    d = os.path.join(HERE, "shard")
+    os.makedirs(d, exist_ok=True)
+    raw, img = 15, 9
+    utts = [("sw02001-A_000098-001156", 7, [3, 1, 4]), ("sw02001-B_001980-002131", 12, [1, 5]),
+            ("sw02005-A_000001-000002", 1, [9]), ("sw02005-B_012345-012999", 21, [2, 2, 7, 1, 30])]
+    feats = [rs.randn(T, raw).astype(np.float32) for _, T, _ in utts]
+    with open(os.path.join(d, "keys1.txt"), "w") as kf, open(os.path.join(d, "alis1.txt"), "w") as af:
+        for name, T, labels in utts:
+            kf.write("%s %d\n" % (name, T))
+            af.write("%s %s\n" % (name, " ".join(str(l) for l in labels)))
+    # Kaldi's export may hold frames beyond sum(sizes) (dataLoader.py:68 slices them off)
+    np.concatenate(feats + [rs.randn(3, raw).astype(np.float32)]).tofile(os.path.join(d, "feats1.bin"))
+    out = {"rawsize": np.int64(raw), "imgsize": np.int64(img)}
+    for tag, im in (("crop", img), ("full", raw)):
+        loader = dataLoader_e.DataLoader(d + "/", raw, im)
+        data_dict, alis, keys, sizes = loader.loadDataFileDict(1)
+        out[tag + "_keys"] = np.array(keys)
+        out[tag + "_sizes"] = np.asarray(sizes)
+        for i, k in enumerate(keys):
+            out["%s_data%d" % (tag, i)] = data_dict[k]
+            out["%s_alis%d" % (tag, i)] = np.array(alis[k])
+        mat, _, _, _ = loader.loadDataFile(1)
+        out[tag + "_mat"] = np.array(mat)
+    np.savez(os.path.join(HERE, "loader_ref.npz"), **out)
+
+
+class Py2Pickler:
+    """Emits what Python 2's cPickle writes at protocol 0 -- the reference's
+    `pickle.dump(obj, fid)` with no protocol argument (sgd.py:42, brnnet.py:267) -- for the object
+    shapes a params.pk holds: int, float, list, and numpy.ndarray (through
+    numpy.core.multiarray._reconstruct + __setstate__ with the raw data as a Python-2 `str`:
+    the S opcode that Python 3 can only read with encoding='latin1')."""
+
+    def __init__(self):
+        self.out = []
+        self.memo = 0
+
+    def put(self):
+        self.out.append(b"p%d\n" % self.memo)
+        self.memo += 1
+
+    @staticmethod
+    def py2_repr(b):
+        q = b'"' if (b"'" in b and b'"' not in b) else b"'"
+        r = bytearray(q)
+        for c in b:
+            ch = bytes([c])
+            if ch == q or ch == b"\\":
+                r += b"\\" + ch
+            elif ch == b"\t":
+                r += b"\\t"
+            elif ch == b"\n":
+                r += b"\\n"
+            elif ch == b"\r":
+                r += b"\\r"
+            elif c < 0x20 or c >= 0x7f:
+                r += b"\\x%02x" % c
+            else:
+                r += ch
+        return bytes(r + q)
+
+    def string(self, b):
+        self.out.append(b"S" + self.py2_repr(b) + b"\n")
+        self.put()
+
+    def integer(self, v):
+        self.out.append(b"I%d\n" % v)
+
+    def save(self, obj):
+        if isinstance(obj, bool):
+            self.out.append(b"I01\n" if obj else b"I00\n")
+        elif isinstance(obj, int):
+            self.integer(obj)
+        elif isinstance(obj, float):
+            self.out.append(b"F" + repr(obj).encode() + b"\n")
+        elif isinstance(obj, list):
+            self.out.append(b"(l")
+            self.put()
+            if obj:
+                self.out.append(b"(")
+                for v in obj:
+                    self.save(v)
+                self.out.append(b"e")
+        elif isinstance(obj, np.ndarray):
+            self.ndarray(obj)
+        else:
+            raise TypeError(type(obj))
+
+    def glob(self, module, name):
+        self.out.append(b"c" + module + b"\n" + name + b"\n")
+        self.put()
+
+    def ndarray(self, a):
+        a = np.ascontiguousarray(a)
+        # numpy's ndarray.__reduce__: (_reconstruct, (ndarray, (0,), 'b'), state)
+        self.glob(b"numpy.core.multiarray", b"_reconstruct")
+        self.out.append(b"(")
+        self.glob(b"numpy", b"ndarray")
+        self.out.append(b"(")
+        self.integer(0)
+        self.out.append(b"t")
+        self.put()
+        self.string(b"b")
+        self.out.append(b"t")
+        self.put()
+        self.out.append(b"R")
+        self.put()
+        # state = (version 1, shape, dtype, is_fortran, rawdata)
+        self.out.append(b"(")
+        self.integer(1)
+        self.out.append(b"(")
+        for n in a.shape:
+            self.integer(int(n))
+        self.out.append(b"t")
+        self.put()
+        self.glob(b"numpy", b"dtype")
+        self.out.append(b"(")
+        self.string(a.dtype.str[1:].encode())        # 'f4'
+        self.integer(0)
+        self.integer(1)
+        self.out.append(b"t")
+        self.put()
+        self.out.append(b"R")
+        self.put()
+        self.out.append(b"(")                          # dtype.__setstate__ tuple
+        self.integer(3)
+        self.string(b"<")
+        self.out.append(b"NNN")
+        self.integer(-1)
+        self.integer(-1)
+        self.integer(0)
+        self.out.append(b"t")
+        self.put()
+        self.out.append(b"b")
+        self.out.append(b"I00\n")                      # C order
+        self.string(a.tobytes())
+        self.out.append(b"t")
+        self.put()
+        self.out.append(b"b")
+
+    def dumps(self, obj):
+        self.out, self.memo = [], 0
+        self.save(obj)
+        self.out.append(b".")
+        return b"".join(self.out)
+
+
+def gen_py2_pickle():
+    """params.pk = SGD pickle [it, costt, expcost, velocity stack] followed by the NNet pickle
+    (list of [w, b] float32 arrays; the temporal pair shares a (1,1) dummy bias) --
+    runNNet.py:181-186 writes both into one file."""
+    rs = np.random.RandomState(21)
+    D, A, H, NL = 6, 5, 8, 2           # temporalLayer 1
+    dims = [D] + [H] * NL + [A]
+    def stack():
+        st = [[rs.randn(m, n).astype(np.float32), rs.randn(m, 1).astype(np.float32)]
+              for n, m in zip(dims[:-1], dims[1:])]
+        for _ in range(2):
+            st.append([rs.randn(H, H).astype(np.float32), np.zeros((1, 1), dtype=np.float32)])
+        return st
+    vel, par = stack(), stack()
+    it, costt, expcost = 17, [float(v) for v in rs.rand(5) * 100], [float(v) for v in rs.rand(5) * 100]
+    pk = Py2Pickler()
+    blob = pk.dumps([it, costt, expcost, vel]) + pk.dumps(par)
+    with open(os.path.join(HERE, "ref_py2_params.pk"), "wb") as f:
+        f.write(blob)
+    out = {"it": np.int64(it), "costt": np.array(costt), "expcost": np.array(expcost),
+           "dims": np.array([D, A, H, NL, 1], dtype=np.int64)}
+    for i, ((vw, vb), (w, b)) in enumerate(zip(vel, par)):
+        out["vw%d" % i], out["vb%d" % i], out["w%d" % i], out["b%d" % i] = vw, vb, w, b
+    np.savez(os.path.join(HERE, "ref_py2_params.npz"), **out)
+    # the stream must be a valid pickle for Python 3 (latin1) and must NEED latin1
+    import io, pickle
+    f = io.BytesIO(blob)
+    a = pickle.load(f, encoding="latin1")
+    b = pickle.load(f, encoding="latin1")
+    assert a[0] == it and np.array_equal(a[3][0][0], vel[0][0]) and np.array_equal(b[-1][0], par[-1][0])
+    try:
+        pickle.load(io.BytesIO(blob))
+        raise AssertionError("a Python-2 str pickle of array data should not load as ASCII")
+    except UnicodeDecodeError:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scratch", default="/tmp/sctc_ref")
@@ -273,6 +484,8 @@ def main():
         gen_mid(cf)
         gen_brnn_main(tw)
         gen_brnn_cfg(tw)
+        gen_loader(a.scratch)
+    gen_py2_pickle()
     for n in sorted(os.listdir(HERE)):
         if n.endswith(".npz"):
             print("%-24s %7.1f KB" % (n, os.path.getsize(os.path.join(HERE, n)) / 1024.0))

@@ -55,3 +55,52 @@ def test_async_prefetch_and_alignment_only(tmp_path):
     only_ali = dl.DataLoader(str(tmp_path) + "/", 6, 6, load_data=False)
     data, alis, keys, sizes = only_ali.loadDataFileDict(1)
     assert data is None and list(keys) == ["a"] and alis["a"] == ["1"]
+
+
+def test_loader_matches_reference_loader(golden):
+    """tests/golden/shard/ read by this loader == what the reference's own dataLoader.py:38-95
+    (converted with lib2to3 in the build container, tests/golden/make_golden.py) returned for it:
+    centre crop and full width, dict and matrix forms, keys, sizes, alignments"""
+    import os
+    import dataLoader as dl
+    from tests.conftest import GOLDEN
+    g = golden("loader_ref.npz")
+    raw, img = int(g["rawsize"]), int(g["imgsize"])
+    for tag, im in (("crop", img), ("full", raw)):
+        loader = dl.DataLoader(os.path.join(GOLDEN, "shard") + "/", raw, im)
+        data_dict, alis, keys, sizes = loader.loadDataFileDict(1)
+        assert list(keys) == [str(k) for k in g[tag + "_keys"]]
+        np.testing.assert_array_equal(np.asarray(sizes), g[tag + "_sizes"])
+        assert np.asarray(sizes).dtype == g[tag + "_sizes"].dtype
+        for i, k in enumerate(keys):
+            ref = g["%s_data%d" % (tag, i)]
+            assert data_dict[k].shape == ref.shape and data_dict[k].dtype == ref.dtype
+            np.testing.assert_array_equal(data_dict[k], ref)
+            assert list(alis[k]) == [str(a) for a in g["%s_alis%d" % (tag, i)]]
+        mat, _, _, _ = loader.loadDataFile(1)
+        np.testing.assert_array_equal(mat, g[tag + "_mat"])
+        # no trailing slash works too (the reference concatenates strings and needs it)
+        loader2 = dl.DataLoader(os.path.join(GOLDEN, "shard"), raw, im)
+        assert list(loader2.loadDataFileDict(1)[2]) == list(keys)
+
+
+def test_py2_checkpoint_fixture_parses(golden):
+    """tests/golden/ref_py2_params.pk is a params.pk in Python-2 cPickle protocol-0 bytes
+    (sgd.py:36-42 + brnnet.py:258-267): it needs encoding='latin1' under Python 3"""
+    import os
+    import pickle
+    from tests.conftest import GOLDEN
+    g = golden("ref_py2_params.npz")
+    with open(os.path.join(GOLDEN, "ref_py2_params.pk"), "rb") as f:
+        with pytest.raises(UnicodeDecodeError):
+            pickle.load(f)
+        f.seek(0)
+        it, costt, expcost, vel = pickle.load(f, encoding="latin1")
+        par = pickle.load(f, encoding="latin1")
+    assert it == int(g["it"])
+    np.testing.assert_array_equal(costt, g["costt"])
+    np.testing.assert_array_equal(expcost, g["expcost"])
+    for i, ((vw, vb), (w, b)) in enumerate(zip(vel, par)):
+        for got, key in ((vw, "vw"), (vb, "vb"), (w, "w"), (b, "b")):
+            assert got.dtype == np.float32
+            np.testing.assert_array_equal(got, g["%s%d" % (key, i)])

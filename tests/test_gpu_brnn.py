@@ -120,7 +120,7 @@ def test_brnn_init_matches_reference_seed(mods, golden):
     assert c == pytest.approx(cost, rel=1e-4)
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
 def test_brnn_scaled_configs(mods, golden, name):
     _, brnnet, _, _ = mods
     params, grads, dims, data, labels, cost = load_net(golden("brnn_cfg.npz"), name + "_")

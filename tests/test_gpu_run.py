@@ -78,8 +78,11 @@ def test_train_resume_and_export(tmp_path):
     np.testing.assert_allclose(np.log(p).T, ark[keys[0]], rtol=1e-5, atol=1e-6)
 
 
-def test_data_parallel_trainer_two_ranks(tmp_path):
-    """runNNet under torch.distributed.run with 2 ranks (gloo, both on the one GPU of the box):
+@pytest.mark.parametrize("reg", [0.0, 0.02])
+def test_data_parallel_trainer_two_ranks(tmp_path, reg):
+    """(reg > 0: the L2 term must enter the update exactly once whatever the number of ranks --
+    it is added after the all-reduce and the 1/n_valid scaling, never per rank)
+    runNNet under torch.distributed.run with 2 ranks (gloo, both on the one GPU of the box):
     every rank processes its share of each minibatch, gradients are all-reduced, rank 0 owns the
     run directory -- and the parameters after one epoch equal those of the single-process run
     with the same minibatch (mean over the same utterances; fp32 summation order aside)."""
@@ -98,7 +101,7 @@ def test_data_parallel_trainer_two_ranks(tmp_path):
     common = ["--layerSize", "32", "--numLayers", "3", "--temporalLayer", "2", "--inputDim", str(img),
               "--rawDim", str(raw), "--outputDim", str(A), "--maxUttLen", "40", "--numFiles", "1",
               "--dataDir", str(data) + "/", "--step", "1e-3", "--momentum", "0.9", "--save_every", "1",
-              "--epochs", "1", "--minibatch", "4"]
+              "--epochs", "1", "--minibatch", "4", "--reg", str(reg)]
     single = tmp_path / "single"
     runNNet.run(common + ["--outputDir", str(single)])
     dp = tmp_path / "dp"
@@ -106,7 +109,7 @@ def test_data_parallel_trainer_two_ranks(tmp_path):
     env = dict(os.environ, SCTC_DIST_BACKEND="gloo", PYTHONPATH=os.pathsep.join(
         [root, os.path.join(root, "stanford-ctc_amd"), os.environ.get("PYTHONPATH", "")]))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29517",
+           "--master-addr", "127.0.0.1", "--master-port", str(29517 + (1 if reg else 0)),
            os.path.join(root, "stanford-ctc_amd", "runNNet.py")] + common + ["--outputDir", str(dp)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]

@@ -154,3 +154,82 @@ def test_sgd_minibatch_mean_gradient():
     assert opt.it == 1
     assert np.linalg.norm(got - w) / np.linalg.norm(w) < 1e-6
     assert opt.costt[0] == pytest.approx(float(np.mean(costs)), rel=1e-4)
+
+
+@pytest.mark.parametrize("mb", [1, 4])
+def test_sgd_l2_term_enters_once(mb):
+    """reg > 0: one step with minibatch 1 (reference semantics: reg*W inside costAndGrad,
+    brnnet.py:197-198,244-247) and with minibatch 4 (reg*W added once after the 1/n_valid
+    scaling) against the oracle's  mean(data gradients) + reg*W ; biases carry no L2 term; the
+    bookkept cost contains the L2 cost in both modes (brnnet.py:178-183)"""
+    from nnets import brnnet
+    import sgd
+    from oracle import brnn as obrnn
+    rs = np.random.RandomState(14)
+    D, A, H, NL, TL, maxT = 10, 6, 32, 2, 1, 24
+    reg = 0.05
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    for b in params["b"]:
+        b += rs.randn(*b.shape)             # non-zero biases: an L2 term on them would show
+    keys = ["a", "b", "c", "d"][:mb]
+    data_dict = {k: rs.randn(D, int(rs.randint(10, maxT))).astype(np.float32) for k in keys}
+    alis = {k: [str(v) for v in rs.randint(1, A, size=2)] for k in keys}
+    net = brnnet.NNet(D, A, H, NL, maxT, temporalLayer=TL, maxUtts=mb, reg=reg)
+    st = [[w, b] for w, b in zip(params["W"], params["b"])] + [[params["Wf"], None], [params["Wb"], None]]
+    net.setParams(st)
+    opt = sgd.SGD(net, maxT, alpha=1e-2, momentum=0.9, maxGradNorm=1e9, minibatch=mb)
+    random.seed(2)
+    order = list(keys)
+    opt.run(data_dict, alis, order)
+    with np.errstate(all="ignore"):
+        costs, g, skips, n_valid = obrnn.cost_and_grad_batch(
+            params, [data_dict[k] for k in order],
+            [np.array(alis[k], dtype=np.int32) for k in order], TL, reg=reg, mean=True)
+    assert n_valid == mb
+    w = flat(params) - 1e-2 * gflat(g)
+    got = np.concatenate([np.concatenate([net.stack[i][0].copy_to_host().ravel(),
+                                          net.stack[i][1].copy_to_host().ravel()])
+                          for i in range(NL + 1)] +
+                         [net.stack[NL + 1][0].copy_to_host().ravel(),
+                          net.stack[NL + 2][0].copy_to_host().ravel()])
+    assert np.linalg.norm(got - w) / np.linalg.norm(w) < 1e-6
+    mats = list(params["W"]) + [params["Wf"], params["Wb"]]
+    regcost = sum(0.5 * reg * float(np.sum(m * m)) for m in mats)
+    assert opt.costt[0] == pytest.approx(float(np.mean(costs)) + regcost, rel=1e-4)
+    assert opt.regcost[0] == pytest.approx(regcost, rel=1e-5)
+    gn = np.linalg.norm(gflat(g))
+    assert opt.last_gnorm == pytest.approx(gn, rel=1e-4)
+
+
+def test_reference_py2_checkpoint_loads(golden):
+    """a params.pk in the reference's own byte format (Python-2 cPickle protocol 0,
+    sgd.py:36-42 + brnnet.py:258-267; tests/golden/ref_py2_params.pk) resumes: SGD state and
+    velocity, then the network weights"""
+    import os
+    from nnets import brnnet
+    import sgd
+    from tests.conftest import GOLDEN
+    g = golden("ref_py2_params.npz")
+    D, A, H, NL, TL = [int(v) for v in g["dims"]]
+    net = brnnet.NNet(D, A, H, NL, 16, temporalLayer=TL)
+    net.initParams()
+    opt = sgd.SGD(net, 16)
+    with open(os.path.join(GOLDEN, "ref_py2_params.pk"), "rb") as f:
+        opt.fromFile(f)
+        net.fromFile(f)
+    assert opt.it == int(g["it"])
+    np.testing.assert_array_equal(opt.costt, g["costt"])
+    np.testing.assert_array_equal(opt.expcost, g["expcost"])
+    for i in range(NL + 3):
+        np.testing.assert_array_equal(net.stack[i][0].copy_to_host(), g["w%d" % i])
+        np.testing.assert_array_equal(opt.velocity[i][0].copy_to_host(), g["vw%d" % i])
+        if i <= NL:
+            np.testing.assert_array_equal(net.stack[i][1].copy_to_host(), g["b%d" % i])
+            np.testing.assert_array_equal(opt.velocity[i][1].copy_to_host(), g["vb%d" % i])
+    # and a forward-only model built from the same file (runNNet.py:215-219 test mode)
+    net2 = brnnet.NNet(D, A, H, NL, 16, train=False, temporalLayer=TL)
+    with open(os.path.join(GOLDEN, "ref_py2_params.pk"), "rb") as f:
+        import pickle as _p
+        _p.load(f, encoding="latin1")
+        net2.fromFile(f)
+    np.testing.assert_array_equal(net2.stack[0][0].copy_to_host(), g["w0"])

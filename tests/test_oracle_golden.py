@@ -68,20 +68,24 @@ def test_ctc_time_trials_known_answer(golden):
 
 def test_ctc_mid_size(golden):
     g = golden("ctc_mid.npz")
-    for T, U in ((1000, 100), (2000, 200)):
+    for T, U in ((1000, 100), (2000, 200), (8000, 800)):
         logits, seq = mid_input(T, 33, U, 0)
         k = "T%d" % T
+        st = 41 if T <= 2000 else 163
         assert logits.sum() == pytest.approx(float(g[k + "_logits_checksum"]), rel=1e-13)
         np.testing.assert_array_equal(seq, g[k + "_seq"])
         cost, grad, skip = octc.ctc_loss(np.asfortranarray(softmax0(logits)), seq)
         assert not skip
         assert cost == pytest.approx(float(g[k + "_cost"]), rel=1e-13)
-        np.testing.assert_allclose(grad[:, ::41], g[k + "_grad_stride41"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(grad[:, ::st], g[k + "_grad_stride41"], rtol=1e-9, atol=1e-13)
+        assert np.abs(grad).sum() == pytest.approx(float(g[k + "_sum_abs_grad"]), rel=1e-10)
         # the logits entry point is the same thing with the softmax inside
         cost2, grad2, skip2, probs2 = octc.ctc_loss_logits(np.asfortranarray(logits), seq)
         assert cost2 == pytest.approx(cost, rel=1e-12)
         np.testing.assert_allclose(grad2, grad, rtol=1e-9, atol=1e-13)
     assert float(g["T1000_cost"]) == pytest.approx(3167.051290, abs=1e-5)
+    assert float(g["T2000_cost"]) == pytest.approx(6302.641853, abs=1e-5)
+    assert float(g["T8000_cost"]) == pytest.approx(25384.546219, abs=1e-5)
 
 
 def test_ctc_skip_cases(golden):
@@ -201,7 +205,7 @@ def test_brnn_main_init_replay(golden):
     np.testing.assert_array_equal(p2["Wb"], params["Wb"])
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
 def test_brnn_scaled_configs(golden, name):
     params, grads, dims, data, labels, cost = load_net(golden("brnn_cfg.npz"), name + "_")
     D, A, H, NL, TL, T = dims
