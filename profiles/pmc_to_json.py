@@ -67,6 +67,8 @@ def main(root):
     steps_pmc = len(mf.get("ctc_lattice_kernel", {}).get("SQ_WAVES", [])) or \
         len(fe.get("ctc_lattice_kernel", {}).get("FETCH_SIZE", []))
     out["costAndGrad_calls"] = {"stats_pass": steps_stats, "pmc_passes": steps_pmc}
+    if len(sys.argv) > 2:
+        out["source_hash"] = sys.argv[2]      # bench.csrc_hash() of the measured tree
     mean = lambda v: sum(v) / len(v) if v else None
     for fam in FAMILIES:
         k = {}

@@ -1,5 +1,5 @@
-"""Randomised differential test of the recurrent kernels (not part of the pytest suite; run with
-`python tests/gpu_fuzz.py [n_cases] [seed]` on the GPU): random layer size, minibatch size,
+"""Randomised differential test of the recurrent kernels (`python tests/gpu_fuzz.py [n_cases] [seed]` on the GPU; tests/test_gpu_fuzz.py runs a 20-case
+subset with a fixed seed in the suite): random layer size, minibatch size,
 ragged lengths and time order; the automatically chosen kernel (sentinel/VALU, sentinel/MFMA,
 two-chain, flag) against the one-workgroup-per-CU flag kernel (SCTC_REC_VARIANT=1) and, for the
 small layer sizes, the float64 oracle."""
@@ -29,9 +29,8 @@ def grads(net, NL):
     return [net.grad[i][0].copy_to_host().astype(np.float64).copy() for i in range(NL + 3)]
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def run(n_cases=40, seed=0):
+    rs = np.random.RandomState(seed)
     worst = 0.0
     for case in range(n_cases):
         H = int(rs.choice([512, 512, 1024, 1824, 2048, 96]))
@@ -97,4 +96,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0)

@@ -1,5 +1,5 @@
-"""Randomised differential test of the CTC kernels against the C oracle (not part of the pytest
-suite; `python tests/gpu_fuzz_ctc.py [n_cases] [seed]` on the GPU): random alphabet, ragged
+"""Randomised differential test of the CTC kernels against the C oracle (`python tests/gpu_fuzz_ctc.py [n_cases] [seed]`
+on the GPU; tests/test_gpu_fuzz.py runs a 20-case subset with a fixed seed in the suite): random alphabet, ragged
 batches, repeats, labels equal to the blank, T < U (empty band), infeasible repeats and
 zero-probability labels (skip), peaked and flat distributions, float32 and float64 I/O,
 one- and four-wave lattices."""
@@ -16,9 +16,8 @@ import ctc_fast  # noqa: E402
 from oracle import ctc as octc  # noqa: E402
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def run(n_cases=60, seed=0):
+    rs = np.random.RandomState(seed)
     worst_c = worst_g = 0.0
     n_skip = n_inf = 0
     for case in range(n_cases):
@@ -73,4 +72,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 0)

@@ -1,5 +1,5 @@
-"""Randomised test of sctc_gemm_f32 (not part of the pytest suite; `python tests/gpu_fuzz_gemm.py
-[n_cases] [seed]` on the GPU): random sizes (multiples of 4, ragged against every tile shape),
+"""Randomised test of sctc_gemm_f32 (`python tests/gpu_fuzz_gemm.py [n_cases] [seed]` on the GPU;
+tests/test_gpu_fuzz.py runs a subset with a fixed seed in the suite): random sizes (multiples of 4, ragged against every tile shape),
 all four operand layouts, padded leading dimensions, bias/ReLU epilogue, with and without split-K
 workspace, against a float64 product."""
 import ctypes
@@ -15,9 +15,8 @@ import torch  # noqa: E402
 import _sctc  # noqa: E402
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def run(n_cases=100, seed=0):
+    rs = np.random.RandomState(seed)
     L = _sctc.lib()
     ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     worst = 0.0
@@ -54,4 +53,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0)

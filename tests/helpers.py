@@ -84,3 +84,90 @@ def load_net(npz, prefix=""):
         grads["Wb"] = npz[prefix + "dW%d" % (NL + 2)]
     return (params, grads, (D, A, H, NL, TL, T), npz[prefix + "data"], npz[prefix + "labels"],
             float(npz[prefix + "cost"]))
+
+
+_ORACLE_CTX = None     # (params, datas, labs, TL, max_act, want_grad): inherited by the forked workers
+
+
+def _oracle_chunk(idx):
+    """worker of oracle_parallel: the utterances `idx` of the inherited problem; returns their
+    costs / skips and the SUM of their gradients (one pickled gradient per worker, not per
+    utterance)"""
+    params, datas, labs, TL, max_act, want_grad = _ORACLE_CTX
+    from oracle import brnn as obrnn
+    from oracle import ctc as octc
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=job_threads())
+    except Exception:
+        import contextlib
+        ctx = contextlib.nullcontext()
+    costs, skips, total = [], [], None
+    with ctx, np.errstate(all="ignore"):
+        for i in idx:
+            data = np.asarray(datas[i], dtype=np.float64)
+            if want_grad:
+                c, g, s, _ = obrnn.cost_and_grad(params, data, labs[i], TL, max_act)
+            else:
+                logits, _ = obrnn.forward(params, data, TL, max_act)
+                c, _, s = octc.ctc_loss(np.asfortranarray(obrnn.softmax_cols(logits)),
+                                        np.ascontiguousarray(labs[i], dtype=np.int32), 0)
+                g = None
+            costs.append(c)
+            skips.append(bool(s))
+            if g is None or s:
+                continue
+            if total is None:
+                total = g
+            else:
+                for a, b in zip(total["W"], g["W"]):
+                    a += b
+                for a, b in zip(total["b"], g["b"]):
+                    a += b
+                total["Wf"] += g["Wf"]
+                total["Wb"] += g["Wb"]
+    return list(idx), costs, skips, total
+
+
+def job_threads():
+    import os
+    return max(1, int(os.environ.get("SCTC_ORACLE_THREADS", "8")))
+
+
+def oracle_parallel(params, datas, labs, TL, max_act=20.0, want_grad=True, procs=None):
+    """the float64 oracle over a list of utterances in forked worker processes (a few BLAS
+    threads each): the full-size configurations take seconds instead of minutes on the GPU
+    box's host.  Returns (costs, summed gradient dict or None, skips)."""
+    global _ORACLE_CTX
+    import multiprocessing as mp
+    import os
+    n = len(datas)
+    procs = procs or max(1, min(n, 16, (os.cpu_count() or 8) // job_threads()))
+    _ORACLE_CTX = (params, datas, labs, TL, max_act, want_grad)
+    chunks = [list(range(k, n, procs)) for k in range(procs)]
+    try:
+        if procs == 1:
+            res = [_oracle_chunk(chunks[0])]
+        else:
+            with mp.get_context("fork").Pool(procs) as pool:
+                res = pool.map(_oracle_chunk, chunks, chunksize=1)
+    finally:
+        _ORACLE_CTX = None
+    costs = np.zeros(n)
+    skips = np.zeros(n, dtype=bool)
+    total = None
+    for idx, c, s, g in res:
+        costs[idx] = c
+        skips[idx] = s
+        if g is None:
+            continue
+        if total is None:
+            total = g
+        else:
+            for a, b in zip(total["W"], g["W"]):
+                a += b
+            for a, b in zip(total["b"], g["b"]):
+                a += b
+            total["Wf"] += g["Wf"]
+            total["Wb"] += g["Wb"]
+    return costs, total, skips

@@ -3,8 +3,9 @@ oracle and the golden vectors produced by the reference's rnnetcpu.py -- the re-
 of ctc_fast/debug-utils/checkgrads.py:20-40 (GPU fp32 vs CPU fp64, same seed, same init).
 
 Tolerances (fp32 device arithmetic vs fp64 oracle): cost 1e-4 relative (north_star),
-gradients 2e-3 relative Frobenius norm per tensor; observed values are
-one to two orders of magnitude tighter and printed by the diagnostics script.
+gradients 1e-4 relative Frobenius norm per tensor at these sizes (observed ~3e-7; SURVEY 8(c)
+allows 1e-3).  The full-size configurations (thousands of dependent fp32 steps) have their own
+stated tolerance in tests/test_gpu_fullsize.py.
 """
 import io
 import pickle
@@ -47,7 +48,7 @@ def make_net(brnnet, dims, params, maxUtts=1, reg=0.0, max_act=20.0, train=True,
     return net
 
 
-def check_grads(net, grads, NL, tol=2e-3):
+def check_grads(net, grads, NL, tol=1e-4):
     worst = 0.0
     for i in range(NL + 1):
         dw, db = net.grad[i]

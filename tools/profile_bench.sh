@@ -20,5 +20,5 @@ for f in mfma fetch write; do python profiles/pmc_summary.py $O/pmc_$f > $O/pmc_
 # keep only small files
 find $O -name "*counter_collection.csv" -size +20M -delete
 find $O -name "*kernel_trace.csv" -size +20M -delete
-python profiles/pmc_to_json.py $O > $O/pmc_summary.json
+python profiles/pmc_to_json.py $O $(python -c "import bench; print(bench.csrc_hash())") > $O/pmc_summary.json
 head -c 1500 $O/pmc_summary.json
