@@ -76,18 +76,25 @@ def cpu_baseline(cfg):
     t1 = _cpu_utt((cfg, 0, 1))
     single = {"value": cfg["T"] / t1, "unit": "frames/s", "cores": 1,
               "sample": "1 utterance of T=%d (cfg-3 shape), %.1f s, one thread" % (cfg["T"], t1)}
-    threads = 4 if ncpu >= 64 else 2
-    procs = max(1, min(32, ncpu // threads))
-    t0 = time.time()
-    with mp.get_context("fork").Pool(procs) as pool:
-        per = pool.map(_cpu_utt, [(cfg, 10 + i, threads) for i in range(procs)])
-    wall = time.time() - t0
-    return {"value": procs * cfg["T"] / wall, "unit": "frames/s", "cores": procs * threads,
-            "kind": "port",
+    # The per-utterance recurrence is 4000 matrix-vector products over a 26.6 MB float64 matrix:
+    # memory-bound, so more processes stop helping early (measured on the GPU box: 32 x 4 threads
+    # ran 35 s per utterance against 2.7 s for ONE thread alone).  Two splits, the better one is
+    # the reported all-core figure.
+    tried = []
+    for procs, threads in ((8, 8), (16, 2)):
+        procs = max(1, min(procs, ncpu // max(1, threads)))
+        t0 = time.time()
+        with mp.get_context("fork").Pool(procs) as pool:
+            per = pool.map(_cpu_utt, [(cfg, 10 + i, threads) for i in range(procs)])
+        wall = time.time() - t0
+        tried.append((procs * cfg["T"] / wall, procs, threads, wall, float(np.mean(per))))
+    best = max(tried)
+    return {"value": best[0], "unit": "frames/s", "cores": best[1] * best[2], "kind": "port",
             "sample": "%d utterances of T=%d (cfg-3 shape) in %d processes x %d BLAS threads "
                       "(%d host cores), %.1f s wall, %.1f s mean per utterance; NumPy f64 BRNN "
-                      "oracle + C CTC oracle" % (procs, cfg["T"], procs, threads, ncpu, wall,
-                                                 float(np.mean(per))),
+                      "oracle + C CTC oracle; splits tried: %s"
+                      % (best[1], cfg["T"], best[1], best[2], ncpu, best[3], best[4],
+                         ", ".join("%dx%d -> %.0f frames/s" % (p, t, v) for v, p, t, _, _ in tried)),
             "single_thread": single}
 
 

