@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SCTC_ABI_VERSION 1
+#define SCTC_ABI_VERSION 2
 
 #define SCTC_OK 0
 #define SCTC_ERR_ARG (-1)       /* bad argument (the reference raises ValueError/AssertionError) */
@@ -40,6 +40,8 @@ extern "C" {
 
 #define SCTC_F32 0
 #define SCTC_F64 1
+#define SCTC_F16 2   /* operand type of the mixed-precision GEMMs / recurrent step (fp32 accumulate) */
+#define SCTC_BF16 3
 
 /* ---- library ---------------------------------------------------------- */
 
@@ -123,6 +125,14 @@ typedef struct sctc_brnn_config {
     float max_act;           /* maxAct = 20.0 (brnnet.py:32); <= 0 disables the ceiling (rnnetcpu.py) */
     float reg;               /* L2 coefficient (brnnet.py:22) */
     int32_t train;           /* 0: forward-only model (train=False) */
+    int32_t operand_dtype;   /* SCTC_F32 (0, default): the reference's fp32 arithmetic everywhere.
+                                SCTC_F16: the "fp16 activations" configuration (BASELINE configs[4]):
+                                the operands of every time-batched contraction and of the
+                                6..16-utterance recurrent step are rounded to 16 bit (float16 in
+                                the forward pass, bfloat16 in the backward pass: deltas need
+                                fp32's exponent range), products exact, accumulation fp32;
+                                parameters, gradients, activations in memory, softmax and the
+                                CTC lattices (float64) are unchanged */
 } sctc_brnn_config;
 
 /* One parameter tensor of `stack` (brnnet.py:58-59,71-72): order
@@ -214,6 +224,15 @@ int sctc_gemm_f32(const float* A_dev, int64_t lda, int32_t a_kcontig, const floa
                   int64_t ldb, int32_t b_kcontig, float* C_dev, int64_t ldc, int32_t M, int32_t N,
                   int32_t K, const float* bias_dev, int32_t relu, void* workspace_dev,
                   size_t workspace_bytes, void* stream);
+
+/* The same contraction with both operands ROUNDED to a 16-bit type (operand_dtype = SCTC_F16 or
+ * SCTC_BF16, round-to-nearest-even) on their way to the matrix cores and fp32 accumulation
+ * (v_mfma_f32_32x32x16_f16 / _bf16): the GEMM of the "fp16 activations" configuration
+ * (BASELINE configs[4]).  Operands and result stay fp32 in memory. */
+int sctc_gemm_h16(const float* A_dev, int64_t lda, int32_t a_kcontig, const float* B_dev,
+                  int64_t ldb, int32_t b_kcontig, float* C_dev, int64_t ldc, int32_t M, int32_t N,
+                  int32_t K, const float* bias_dev, int32_t relu, int32_t operand_dtype,
+                  void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---- what sgd.py needs from cudamat objects (sgd.py:21-23,93-106,129-141,161) ---- */
 

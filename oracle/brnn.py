@@ -42,6 +42,59 @@ def init_params(input_dim, output_dim, layer_size, num_layers, temporal_layer, r
     return p
 
 
+def round_f16(x):
+    """round-to-nearest-even to float16 and back (v_cvt_pk_f16_f32 of the mixed-precision path)"""
+    return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float64)
+
+
+def round_bf16(x):
+    """round-to-nearest-even to bfloat16 and back (v_cvt_pk_bf16_f32)"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).astype(np.float64).reshape(np.shape(x))
+
+
+class Mixed:
+    """Numerics of the "fp16 activations" configuration (BASELINE configs[4]) restated: every
+    time-batched contraction rounds BOTH operands to 16 bit (float16 in the forward pass,
+    bfloat16 in the backward pass) and accumulates exactly; `rec` says whether the recurrent
+    time step does the same (the 6..16-utterance kernel) or stays fp32 (the other kernels).
+    Everything else -- biases, clips, masks, softmax, CTC -- is unrounded."""
+
+    def __init__(self, rec=True):
+        self.rec = rec
+        self._cache = {}     # rounded weight matrices (the first operand of fwd / rec_*), by buffer
+
+    def _w(self, w, fn):
+        key = (fn.__name__, w.__array_interface__["data"][0], w.shape, w.strides)
+        hit = self._cache.get(key)
+        if hit is None:
+            hit = (w, fn(w))                 # keeps `w` alive: the address stays unique
+            self._cache[key] = hit
+        return hit[1]
+
+    def fwd(self, w, x):
+        return self._w(w, round_f16) @ round_f16(x)
+
+    def bwd(self, a, b):
+        return round_bf16(a) @ round_bf16(b)
+
+    def rec_fwd(self, w, x):
+        return self._w(w, round_f16) @ round_f16(x) if self.rec else w @ x
+
+    def rec_bwd(self, w, x):
+        return self._w(w, round_bf16) @ round_bf16(x) if self.rec else w @ x
+
+
+class _Exact:
+    rec = False
+
+    @staticmethod
+    def fwd(a, b):
+        return a @ b
+    bwd = rec_fwd = rec_bwd = fwd
+
+
 def _clip(x, max_act):
     x = np.maximum(x, 0.0)
     if max_act is not None:
@@ -56,8 +109,10 @@ def _open_mask(h, max_act):
     return m.astype(h.dtype)
 
 
-def forward(params, data, temporal_layer, max_act=20.0):
-    """Returns (logits, cache).  data: (D_in, T)."""
+def forward(params, data, temporal_layer, max_act=20.0, mixed=None):
+    """Returns (logits, cache).  data: (D_in, T).  mixed: a Mixed() instance restates the
+    16-bit-operand numerics, None = the reference's arithmetic."""
+    mp = mixed or _Exact
     W, b = params["W"], params["b"]
     NL = len(W) - 1
     TL = temporal_layer if 0 < temporal_layer < NL else -1
@@ -65,7 +120,7 @@ def forward(params, data, temporal_layer, max_act=20.0):
     acts = [np.asarray(data, dtype=np.float64)]
     hF = hB = None
     for i in range(1, NL + 2):
-        z = W[i - 1] @ acts[i - 1] + b[i - 1]
+        z = mp.fwd(W[i - 1], acts[i - 1]) + b[i - 1]
         if i == TL:
             Wf, Wb = params["Wf"], params["Wb"]
             hF = np.zeros_like(z)
@@ -73,9 +128,9 @@ def forward(params, data, temporal_layer, max_act=20.0):
             hF[:, 0] = _clip(z[:, 0], max_act)
             hB[:, T - 1] = _clip(z[:, T - 1], max_act)
             for t in range(1, T):
-                hF[:, t] = _clip(z[:, t] + Wf @ hF[:, t - 1], max_act)
+                hF[:, t] = _clip(z[:, t] + mp.rec_fwd(Wf, hF[:, t - 1]), max_act)
                 u = T - 1 - t
-                hB[:, u] = _clip(z[:, u] + Wb @ hB[:, u + 1], max_act)
+                hB[:, u] = _clip(z[:, u] + mp.rec_fwd(Wb, hB[:, u + 1]), max_act)
             acts.append(hF + hB)
         elif i <= NL:
             acts.append(np.maximum(z, 0.0))
@@ -89,12 +144,13 @@ def softmax_cols(logits):
     return e / e.sum(axis=0, keepdims=True)
 
 
-def cost_and_grad(params, data, labels, temporal_layer, max_act=20.0, reg=0.0, blank=0):
+def cost_and_grad(params, data, labels, temporal_layer, max_act=20.0, reg=0.0, blank=0, mixed=None):
     """One utterance.  Returns (cost, grads, skip, probs) with ``grads`` shaped
     like ``params`` (dW list, db list, dWf, dWb).  On skip, grads is None (the
     reference returns its stale buffers, brnnet.py:185-186)."""
+    mp = mixed or _Exact
     W = params["W"]
-    logits, cache = forward(params, data, temporal_layer, max_act)
+    logits, cache = forward(params, data, temporal_layer, max_act, mixed)
     acts, hF, hB, TL, NL = cache["acts"], cache["hF"], cache["hB"], cache["TL"], cache["NL"]
     T = data.shape[1]
     probs = softmax_cols(logits)
@@ -113,13 +169,13 @@ def cost_and_grad(params, data, labels, temporal_layer, max_act=20.0, reg=0.0, b
     dWf = dWb = None
     d_in = np.array(delta)                                # (A, T)
     for i in range(NL, -1, -1):                           # brnnet.py:191-243
-        dW[i] = d_in @ acts[i].T
+        dW[i] = mp.bwd(d_in, acts[i].T)
         if reg > 0:
             dW[i] = dW[i] + reg * W[i]
         db[i] = d_in.sum(axis=1, keepdims=True)
         if i == 0:
             break
-        d_out = W[i].T @ d_in
+        d_out = mp.bwd(W[i].T, d_in)
         if i == TL:
             Wf, Wb = params["Wf"], params["Wb"]
             mF, mB = _open_mask(hF, max_act), _open_mask(hB, max_act)
@@ -129,10 +185,10 @@ def cost_and_grad(params, data, labels, temporal_layer, max_act=20.0, reg=0.0, b
             dB[:, 0] *= mB[:, 0]
             for t in range(1, T):
                 u = T - 1 - t
-                dF[:, u] = (dF[:, u] + Wf.T @ dF[:, u + 1]) * mF[:, u]
-                dB[:, t] = (dB[:, t] + Wb.T @ dB[:, t - 1]) * mB[:, t]
-            dWf = dF[:, 1:] @ hF[:, :-1].T                # brnnet.py:227-228
-            dWb = dB[:, :-1] @ hB[:, 1:].T                # brnnet.py:229-230
+                dF[:, u] = (dF[:, u] + mp.rec_bwd(Wf.T, dF[:, u + 1])) * mF[:, u]
+                dB[:, t] = (dB[:, t] + mp.rec_bwd(Wb.T, dB[:, t - 1])) * mB[:, t]
+            dWf = mp.bwd(dF[:, 1:], hF[:, :-1].T)         # brnnet.py:227-228
+            dWb = mp.bwd(dB[:, :-1], hB[:, 1:].T)         # brnnet.py:229-230
             if reg > 0:
                 dWf = dWf + reg * Wf
                 dWb = dWb + reg * Wb
@@ -145,13 +201,13 @@ def cost_and_grad(params, data, labels, temporal_layer, max_act=20.0, reg=0.0, b
 
 
 def cost_and_grad_batch(params, data_list, label_list, temporal_layer, max_act=20.0, reg=0.0,
-                        mean=False):
+                        mean=False, mixed=None):
     """Sum (or mean over non-skipped, ctc/nnet.py:106-124 convention) of
     per-utterance gradients -- the data-parallel parity target of SURVEY 8(e)."""
     total = None
     costs, skips = [], []
     for x, lab in zip(data_list, label_list):
-        c, g, s, _ = cost_and_grad(params, x, lab, temporal_layer, max_act, reg=0.0)
+        c, g, s, _ = cost_and_grad(params, x, lab, temporal_layer, max_act, reg=0.0, mixed=mixed)
         costs.append(c)
         skips.append(s)
         if s:

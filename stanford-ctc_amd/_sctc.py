@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCTC_LIB_PATH") or os.path.join(_HERE, "libsctc_hip.so")   # override: kernel-variant experiments
 
-F32, F64 = 0, 1
+F32, F64, F16, BF16 = 0, 1, 2, 3
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
@@ -29,7 +29,8 @@ class BrnnConfig(ctypes.Structure):
                 ("layer_size", ctypes.c_int32), ("num_layers", ctypes.c_int32),
                 ("temporal_layer", ctypes.c_int32), ("max_frames", ctypes.c_int32),
                 ("max_utts", ctypes.c_int32), ("max_act", ctypes.c_float),
-                ("reg", ctypes.c_float), ("train", ctypes.c_int32)]
+                ("reg", ctypes.c_float), ("train", ctypes.c_int32),
+                ("operand_dtype", ctypes.c_int32)]
 
 
 class TensorInfo(ctypes.Structure):
@@ -83,6 +84,10 @@ PROTOTYPES = {
                                      ctypes.c_int32, vp, ctypes.c_int64, ctypes.c_int32,
                                      ctypes.c_int32, ctypes.c_int32, vp, ctypes.c_int32, vp,
                                      ctypes.c_size_t, vp]),
+    "sctc_gemm_h16": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int32, vp, ctypes.c_int64,
+                                     ctypes.c_int32, vp, ctypes.c_int64, ctypes.c_int32,
+                                     ctypes.c_int32, ctypes.c_int32, vp, ctypes.c_int32,
+                                     ctypes.c_int32, vp, ctypes.c_size_t, vp]),
     "sctc_axpy": (ctypes.c_int, [vp, vp, ctypes.c_float, ctypes.c_int64, vp]),
     "sctc_scale": (ctypes.c_int, [vp, ctypes.c_float, ctypes.c_int64, vp]),
     "sctc_sumsq": (ctypes.c_int, [vp, ctypes.c_int64, vp, vp, ctypes.c_size_t, vp]),
@@ -126,7 +131,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if L.sctc_abi_version() != 1:
+        if L.sctc_abi_version() != 2:
             raise ImportError("libsctc_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -108,6 +108,8 @@ static int derive_dims(const sctc_brnn_config* c, Dims* d)
                    c->input_dim, c->output_dim, c->layer_size, c->num_layers);
     SCTC_CHECK_ARG(c->max_frames >= 1 && c->max_utts >= 1, "brnn: bad capacity");
     SCTC_CHECK_ARG(c->output_dim <= 256, "brnn: alphabet %d > 256", c->output_dim);
+    SCTC_CHECK_ARG(c->operand_dtype == SCTC_F32 || c->operand_dtype == SCTC_F16,
+                   "brnn: operand_dtype must be SCTC_F32 or SCTC_F16 (got %d)", c->operand_dtype);
     d->D = c->input_dim;
     d->H = c->layer_size;
     d->A = c->output_dim;
@@ -199,11 +201,11 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
         for (int l = 0; l <= d.NL; ++l) {
             const int inp = l == 0 ? d.Dp : d.Hp, outp = l == d.NL ? d.Ap : d.Hp;
             int sp = 1;
-            sk = std::max<int64_t>(sk, gemm_plan_splits(outp, inp, (int)F, &sp));
+            sk = std::max<int64_t>(sk, gemm_plan_splits(outp, inp, (int)F, &sp, c->operand_dtype ? 2 : 0));
         }
         if (d.TL > 0) {
             int sp = 1;
-            sk = std::max<int64_t>(sk, gemm_plan_splits(d.Hp, d.Hp, (int)F, &sp));
+            sk = std::max<int64_t>(sk, gemm_plan_splits(d.Hp, d.Hp, (int)F, &sp, c->operand_dtype ? 2 : 0));
         }
     }
     // small minibatches (few row tiles) split K in the forward / delta-propagation GEMMs as well:
@@ -360,7 +362,7 @@ static GemmArgs gemm_defaults()
 static void maybe_split(const sctc_brnn* h, GemmArgs& g)
 {
     int sp = 1;
-    const int64_t need = gemm_plan_splits(g.M, g.N, g.K, &sp);
+    const int64_t need = gemm_plan_splits(g.M, g.N, g.K, &sp, g.prec);
     if (sp > 1 && h->splitk_ws && need <= h->splitk_floats) {
         g.splits = sp;
         g.splitk_ws = h->splitk_ws;
@@ -401,6 +403,7 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
         g.C = dst;
         g.ldc = LD(outp);
         g.relu = (i <= h->NL && i != h->TL) ? 1 : 0;             // brnnet.py:155-157
+        g.prec = h->cfg.operand_dtype == SCTC_F16 ? 1 : 0;       // forward: float16 operands
         maybe_split(h, g);
         SCTC_TRY(launch_gemm_f32(g, s));
         if (i == h->TL) {
@@ -432,6 +435,7 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
             r.variant = h->rec_variant;
             r.poll_delay = h->rec_poll_delay;
             r.debug = h->rec_debug_on ? h->rec_debug : nullptr;
+            r.prec16 = h->cfg.operand_dtype == SCTC_F16;
             SCTC_TRY(launch_recurrent(r, s));
             pt.begin(SCTC_PHASE_OTHER);
             // hActs[i] = hActsFor + hActsBack, brnnet.py:153
@@ -513,6 +517,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
     const int64_t N = h->N;
     const int acc = (flags & SCTC_FLAG_ACCUMULATE) ? 1 : 0;
     const float reg = (flags & SCTC_FLAG_NO_REG_GRAD) ? 0.f : h->cfg.reg;
+    const int bprec = h->cfg.operand_dtype == SCTC_F16 ? 2 : 0;   // backward: bfloat16 operands
     const float* d_in = h->dlogits;
     int d_in_ld = LD(h->Ap);
     float* bufs[2] = {h->dA, h->dBuf};
@@ -542,8 +547,9 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             // db = deltasIn.sum(axis=1), brnnet.py:200: column sums of the A operand, fused
             g.colsum_a = h->grads + h->tinfo[bias_index(h, i)].offset;
             g.splitk_ws = h->splitk_ws;
+            g.prec = bprec;
             int splits = 1;
-            gemm_plan_splits(g.M, g.N, g.K, &splits);
+            gemm_plan_splits(g.M, g.N, g.K, &splits, g.prec);
             g.splits = splits;
             SCTC_TRY(launch_gemm_f32(g, s));
         }
@@ -565,6 +571,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             g.C = d_out;
             g.ldc = LD(inp);
             if (i != h->TL) { g.mask = h->act[i]; g.ldmask = LD(h->Hp); }
+            g.prec = bprec;
             maybe_split(h, g);
             SCTC_TRY(launch_gemm_f32(g, s));
         }
@@ -598,6 +605,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             r.variant = h->rec_variant;
             r.poll_delay = h->rec_poll_delay;
             r.debug = h->rec_debug_on ? h->rec_debug + REC_DEBUG_WORDS : nullptr;
+            r.prec16 = h->cfg.operand_dtype == SCTC_F16;
             SCTC_TRY(launch_recurrent(r, s));
             pt.begin(SCTC_PHASE_BWD_GEMM);
             // dwtf = deltasFor[:,1:T] . hActsFor[:,0:T-1]^T ; dwtb = deltasBack[:,0:T-1] . hActsBack[:,1:T]^T
@@ -631,8 +639,9 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
                     g.add_scale = reg;
                 }
                 g.splitk_ws = h->splitk_ws;
+                g.prec = bprec;
                 int splits = 1;
-                gemm_plan_splits(g.M, g.N, std::max(g.K, 1), &splits);
+                gemm_plan_splits(g.M, g.N, std::max(g.K, 1), &splits, g.prec);
                 g.splits = splits;
                 SCTC_TRY(launch_gemm_f32(g, s));
             }

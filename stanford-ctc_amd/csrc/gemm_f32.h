@@ -39,10 +39,17 @@ struct GemmArgs {
     // [splits][M] column-sum partials)
     float* splitk_ws;
     int32_t splits;
+    // operand precision: 0 = fp32 (v_mfma_f32_32x32x2_f32, exact fp32 fma chain);
+    // 1 = float16, 2 = bfloat16: both operands rounded to 16 bit on the way into LDS, fp32
+    // accumulate (gemm_h16.hip; the "fp16 activations" configuration)
+    int32_t prec;
 };
 
 // picks the split-K factor; returns the workspace floats needed (0 when splits == 1)
-int64_t gemm_plan_splits(int M, int N, int K, int* splits);
-int launch_gemm_f32(GemmArgs a, hipStream_t stream);
+int64_t gemm_plan_splits(int M, int N, int K, int* splits, int prec = 0);
+int launch_gemm_f32(GemmArgs a, hipStream_t stream);     // dispatches on a.prec
+// gemm_h16.hip
+int64_t gemm_h16_plan_splits(int M, int N, int K, int* splits);
+int launch_gemm_h16_tiles(const GemmArgs& a, hipStream_t stream);
 
 }  // namespace sctc

@@ -398,8 +398,9 @@ int gemm_pick_shape(int M, int N)
     return best;
 }
 
-int64_t gemm_plan_splits(int M, int N, int K, int* splits)
+int64_t gemm_plan_splits(int M, int N, int K, int* splits, int prec)
 {
+    if (prec) return gemm_h16_plan_splits(M, N, K, splits);
     const ShapeInfo& sh = kShapes[gemm_pick_shape(M, N)];
     const int mt = (M + sh.bm - 1) / sh.bm, nt = (N + sh.bn - 1) / sh.bn;
     const int ktiles = (K + BK - 1) / BK;
@@ -460,9 +461,14 @@ int launch_gemm_f32(GemmArgs a, hipStream_t stream)
     else SCTC_CHECK_ARG(a.N % 4 == 0, "gemm: N must be a multiple of 4 (B row-contig)");
     if (a.splits < 1) a.splits = 1;
     if (a.splits > 1) SCTC_CHECK_ARG(a.splitk_ws != nullptr, "gemm: split-K without workspace");
-    switch (gemm_pick_shape(a.M, a.N)) {
-        case 1: SCTC_TRY(launch_tiles<1>(a, stream)); break;
-        default: SCTC_TRY(launch_tiles<0>(a, stream)); break;
+    if (a.prec) {
+        SCTC_CHECK_ARG(a.prec == 1 || a.prec == 2, "gemm: unknown operand precision %d", a.prec);
+        SCTC_TRY(launch_gemm_h16_tiles(a, stream));
+    } else {
+        switch (gemm_pick_shape(a.M, a.N)) {
+            case 1: SCTC_TRY(launch_tiles<1>(a, stream)); break;
+            default: SCTC_TRY(launch_tiles<0>(a, stream)); break;
+        }
     }
     if (a.splits > 1) {
         const int64_t total = (int64_t)a.M * a.N;
@@ -476,22 +482,50 @@ int launch_gemm_f32(GemmArgs a, hipStream_t stream)
 }  // namespace sctc
 
 // ---- C ABI: cm.dot(A, B, target=C) of cudamat as used by brnnet.py:140,196,204,227-230
+static int gemm_entry(const float* A_dev, int64_t lda, int32_t a_kcontig, const float* B_dev,
+                      int64_t ldb, int32_t b_kcontig, float* C_dev, int64_t ldc, int32_t M, int32_t N,
+                      int32_t K, const float* bias_dev, int32_t relu, void* workspace_dev,
+                      size_t workspace_bytes, void* stream, int prec);
+
+extern "C" int sctc_gemm_h16(const float* A_dev, int64_t lda, int32_t a_kcontig, const float* B_dev,
+                             int64_t ldb, int32_t b_kcontig, float* C_dev, int64_t ldc, int32_t M,
+                             int32_t N, int32_t K, const float* bias_dev, int32_t relu,
+                             int32_t operand_dtype, void* workspace_dev, size_t workspace_bytes,
+                             void* stream)
+{
+    using namespace sctc;
+    SCTC_CHECK_ARG(operand_dtype == SCTC_F16 || operand_dtype == SCTC_BF16,
+                   "gemm_h16: operand_dtype must be SCTC_F16 or SCTC_BF16");
+    return gemm_entry(A_dev, lda, a_kcontig, B_dev, ldb, b_kcontig, C_dev, ldc, M, N, K, bias_dev,
+                      relu, workspace_dev, workspace_bytes, stream, operand_dtype == SCTC_F16 ? 1 : 2);
+}
+
 extern "C" int sctc_gemm_f32(const float* A_dev, int64_t lda, int32_t a_kcontig,
                              const float* B_dev, int64_t ldb, int32_t b_kcontig, float* C_dev,
                              int64_t ldc, int32_t M, int32_t N, int32_t K, const float* bias_dev,
                              int32_t relu, void* workspace_dev, size_t workspace_bytes,
                              void* stream)
 {
+    return gemm_entry(A_dev, lda, a_kcontig, B_dev, ldb, b_kcontig, C_dev, ldc, M, N, K, bias_dev,
+                      relu, workspace_dev, workspace_bytes, stream, 0);
+}
+
+static int gemm_entry(const float* A_dev, int64_t lda, int32_t a_kcontig, const float* B_dev,
+                      int64_t ldb, int32_t b_kcontig, float* C_dev, int64_t ldc, int32_t M, int32_t N,
+                      int32_t K, const float* bias_dev, int32_t relu, void* workspace_dev,
+                      size_t workspace_bytes, void* stream, int prec)
+{
     using namespace sctc;
-    SCTC_CHECK_ARG(A_dev && B_dev && C_dev, "gemm_f32: null pointer");
+    SCTC_CHECK_ARG(A_dev && B_dev && C_dev, "gemm: null pointer");
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = A_dev; g.lda = lda; g.a_kcontig = a_kcontig;
     g.B = B_dev; g.ldb = ldb; g.b_kcontig = b_kcontig;
     g.C = C_dev; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias_dev; g.relu = relu;
+    g.prec = prec;
     int splits = 1;
-    const int64_t need = gemm_plan_splits(M, N, K, &splits);
+    const int64_t need = gemm_plan_splits(M, N, K, &splits, prec);
     if (splits > 1 && workspace_dev && workspace_bytes >= (size_t)need * sizeof(float)) {
         g.splits = splits;
         g.splitk_ws = (float*)workspace_dev;

@@ -1,0 +1,357 @@
+// Mixed-precision GEMM for the "fp16 activations" configuration (BASELINE configs[4], cfg-5):
+// the same contractions as gemm_f32.hip (brnnet.py:140 fwd, :196 wgrad, :204 dgrad,
+// :227-230 recurrent wgrad) with BOTH operands rounded to a 16-bit type on their way into
+// LDS and fp32 accumulation on the matrix cores:
+//   prec 1: float16  (v_mfma_f32_32x32x16_f16)   -- forward pass (activations in [0, 20])
+//   prec 2: bfloat16 (v_mfma_f32_32x32x16_bf16)  -- backward pass (deltas need fp32's exponent range)
+// Master weights, activations, deltas and gradients stay fp32 in HBM; the rounding happens in
+// registers (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round-to-nearest-even), so the numerics are
+// exactly "operands rounded to 16 bit, exact products, fp32 sums".
+//
+// The 16-bit MFMA runs 16x faster than the fp32 one (2.5 PFLOP/s dense): this kernel is bound
+// by operand traffic, not by the matrix pipes.  Tile 128x128x32, 256 threads = 2x2 waves of
+// 64x64 (2x2 MFMA tiles of 32x32x16), 3 blocks per CU so that one block's loads overlap the
+// others' MFMAs.  LDS image of both operands: [row][k] halves with a row stride of 40 halves
+// (80 B): a fragment (lane l: row l&31, 8 consecutive k at 8*(l>>5)) is ONE ds_read_b128.
+//   K-contiguous operand  : float4 = 4 k of one row -> 4 halves -> one ds_write_b64;
+//   row-contiguous operand: every thread loads a 4(k) x 4(row) micro-tile (4 float4, lanes
+//     spread over 8 k-quads x 8 row-quads: 128-byte global segments), transposes it in
+//     registers and writes 4 x ds_write_b64 (conflict-free with this lane order).
+#include "common.h"
+#include "gemm_f32.h"
+
+namespace sctc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int HBM = 128, HBN = 128, HBK = 32;
+static constexpr int HLD = HBK + 8;      // LDS row stride in halves (80 B)
+#ifndef SCTC_H16_OCC
+#define SCTC_H16_OCC 3
+#endif
+static constexpr int H_OCC = SCTC_H16_OCC;
+
+template <bool BF> struct H16;
+template <> struct H16<false> {
+    using V8 = h16x8;
+    using V4 = h16x4;
+    static __device__ __forceinline__ V4 cvt(float a, float b, float c, float d)
+    {
+        V4 v = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
+        return v;
+    }
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct H16<true> {
+    using V8 = b16x8;
+    using V4 = b16x4;
+    static __device__ __forceinline__ V4 cvt(float a, float b, float c, float d)
+    {
+        V4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+        return v;
+    }
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <bool AK, bool BKC, bool BF>
+__global__ __launch_bounds__(256, H_OCC) void gemm_h16_kernel(GemmArgs p)
+{
+    using HT = H16<BF>;
+    using V8 = typename HT::V8;
+    using V4 = typename HT::V4;
+    extern __shared__ __attribute__((aligned(16))) unsigned short hsmem[];
+    constexpr int OP = HBM * HLD;                 // halves per operand per buffer (HBM == HBN)
+    unsigned short* As = hsmem;                   // [2][128][HLD]
+    unsigned short* Bs = hsmem + 2 * OP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = p.M, N = p.N, K = p.K;
+    const int mt = (M + HBM - 1) / HBM, nt = (N + HBN - 1) / HBN;
+    const int nblk = mt * nt;
+    int swz;   // XCD-aware, bijective remap (block b runs on XCD b % 8)
+    {
+        const int bid = blockIdx.x, q = nblk / 8, r = nblk % 8, xcd = bid % 8;
+        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int tile_n = swz % nt, tile_m = swz / nt;
+    const int m0 = tile_m * HBM, n0 = tile_n * HBN;
+    const int ktiles = (K + HBK - 1) / HBK;
+    const int per = (ktiles + p.splits - 1) / p.splits;
+    const int kt_beg = blockIdx.y * per;
+    const int kt_end = min(ktiles, kt_beg + per);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool do_colsum = !AK && p.colsum_a != nullptr && tile_n == 0;
+    float asum[4] = {0.f, 0.f, 0.f, 0.f};    // row-contiguous A: sums over k of this thread's 4 rows
+
+    if (kt_beg < kt_end) {
+        float4 ra[4], rb[4];
+        const int Kc4 = (K - 1) & ~3, Kc1 = K - 1;
+        // K-contiguous: item q -> row (tid + 256 q) / 8, k quad (tid & 7)
+        // row-contiguous: k quad = tid & 7, row quad = tid >> 3
+        const int kq = tid & 7;
+        const float* pa[4];
+        const float* pb[4];
+        int ia[4], ib[4];
+        if constexpr (AK) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                pa[q] = p.A + (int64_t)min(m0 + ((tid + 256 * q) >> 3), M - 1) * p.lda;
+        } else {
+            pa[0] = p.A + min(m0 + 4 * (tid >> 3), (M - 1) & ~3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = min(kt_beg * HBK + 4 * kq + j, Kc1);
+                ia[j] = p.idx_a ? p.idx_a[k] : k;
+            }
+        }
+        if constexpr (BKC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                pb[q] = p.B + (int64_t)min(n0 + ((tid + 256 * q) >> 3), N - 1) * p.ldb;
+        } else {
+            pb[0] = p.B + min(n0 + 4 * (tid >> 3), (N - 1) & ~3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = min(kt_beg * HBK + 4 * kq + j, Kc1);
+                ib[j] = p.idx_b ? p.idx_b[k] : k;
+            }
+        }
+        auto gload = [&](int kt) {
+            const int k0 = kt * HBK;
+            if constexpr (AK) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    ra[q] = *reinterpret_cast<const float4*>(pa[q] + min(k0 + 4 * kq, Kc4));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ra[j] = *reinterpret_cast<const float4*>(pa[0] + (uint32_t)ia[j] * (uint32_t)p.lda);
+                    const int kn = min(k0 + HBK + 4 * kq + j, Kc1);
+                    ia[j] = p.idx_a ? p.idx_a[kn] : kn;     // row of the NEXT tile, one tile ahead
+                }
+            }
+            if constexpr (BKC) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    rb[q] = *reinterpret_cast<const float4*>(pb[q] + min(k0 + 4 * kq, Kc4));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    rb[j] = *reinterpret_cast<const float4*>(pb[0] + (uint32_t)ib[j] * (uint32_t)p.ldb);
+                    const int kn = min(k0 + HBK + 4 * kq + j, Kc1);
+                    ib[j] = p.idx_b ? p.idx_b[kn] : kn;
+                }
+            }
+        };
+        auto zero4 = [](float4& v) { v.x = 0.f; v.y = 0.f; v.z = 0.f; v.w = 0.f; };
+        // registers -> LDS image [row][k] of K tile kt (rounded to 16 bit here)
+        auto lstore = [&](int buf, int kt) {
+            unsigned short* a = As + buf * OP;
+            unsigned short* b = Bs + buf * OP;
+            const bool tail = (kt + 1) * HBK > K;     // uniform
+            if constexpr (AK) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (tail && kt * HBK + 4 * kq >= K) zero4(ra[q]);    // K % 4 == 0 here
+                    const int r = (tid + 256 * q) >> 3;
+                    *reinterpret_cast<V4*>(a + r * HLD + 4 * kq) = HT::cvt(ra[q].x, ra[q].y, ra[q].z, ra[q].w);
+                }
+            } else {
+                if (tail) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (kt * HBK + 4 * kq + j >= K) zero4(ra[j]);
+                }
+                const int r = 4 * (tid >> 3);
+                *reinterpret_cast<V4*>(a + (r + 0) * HLD + 4 * kq) = HT::cvt(ra[0].x, ra[1].x, ra[2].x, ra[3].x);
+                *reinterpret_cast<V4*>(a + (r + 1) * HLD + 4 * kq) = HT::cvt(ra[0].y, ra[1].y, ra[2].y, ra[3].y);
+                *reinterpret_cast<V4*>(a + (r + 2) * HLD + 4 * kq) = HT::cvt(ra[0].z, ra[1].z, ra[2].z, ra[3].z);
+                *reinterpret_cast<V4*>(a + (r + 3) * HLD + 4 * kq) = HT::cvt(ra[0].w, ra[1].w, ra[2].w, ra[3].w);
+                if (do_colsum) {     // bias gradient: exact fp32 sums of the unrounded deltas
+                    asum[0] += (ra[0].x + ra[1].x) + (ra[2].x + ra[3].x);
+                    asum[1] += (ra[0].y + ra[1].y) + (ra[2].y + ra[3].y);
+                    asum[2] += (ra[0].z + ra[1].z) + (ra[2].z + ra[3].z);
+                    asum[3] += (ra[0].w + ra[1].w) + (ra[2].w + ra[3].w);
+                }
+            }
+            if constexpr (BKC) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (tail && kt * HBK + 4 * kq >= K) zero4(rb[q]);
+                    const int r = (tid + 256 * q) >> 3;
+                    *reinterpret_cast<V4*>(b + r * HLD + 4 * kq) = HT::cvt(rb[q].x, rb[q].y, rb[q].z, rb[q].w);
+                }
+            } else {
+                if (tail) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (kt * HBK + 4 * kq + j >= K) zero4(rb[j]);
+                }
+                const int r = 4 * (tid >> 3);
+                *reinterpret_cast<V4*>(b + (r + 0) * HLD + 4 * kq) = HT::cvt(rb[0].x, rb[1].x, rb[2].x, rb[3].x);
+                *reinterpret_cast<V4*>(b + (r + 1) * HLD + 4 * kq) = HT::cvt(rb[0].y, rb[1].y, rb[2].y, rb[3].y);
+                *reinterpret_cast<V4*>(b + (r + 2) * HLD + 4 * kq) = HT::cvt(rb[0].z, rb[1].z, rb[2].z, rb[3].z);
+                *reinterpret_cast<V4*>(b + (r + 3) * HLD + 4 * kq) = HT::cvt(rb[0].w, rb[1].w, rb[2].w, rb[3].w);
+            }
+        };
+
+        gload(kt_beg);
+        lstore(0, kt_beg);
+        __syncthreads();
+        int buf = 0;
+        const int li = lane & 31, kg = lane >> 5;
+        for (int kt = kt_beg; kt < kt_end; ++kt) {
+            const bool more = kt + 1 < kt_end;
+            if (more) gload(kt + 1);          // in flight behind this tile's MFMAs
+            const unsigned short* a = As + buf * OP + (wm * 64 + li) * HLD + 8 * kg;
+            const unsigned short* b = Bs + buf * OP + (wn * 64 + li) * HLD + 8 * kg;
+#pragma unroll
+            for (int ks = 0; ks < HBK / 16; ++ks) {
+                V8 af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const V8*>(a + i * 32 * HLD + 16 * ks);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const V8*>(b + j * 32 * HLD + 16 * ks);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = HT::mfma(af[i], bf[j], acc[i][j]);
+            }
+            if (more) lstore(buf ^ 1, kt + 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    if constexpr (!AK) {
+        if (do_colsum) {   // block-uniform
+            // the 8 lanes that share a row quad (lane bits 0..2 = k quad) hold partial sums
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = asum[e];
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64);
+                asum[e] = v;
+            }
+            if ((tid & 7) == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = m0 + 4 * (tid >> 3) + e;
+                    if (m < M) {
+                        if (p.splits > 1)
+                            p.splitk_ws[(int64_t)p.splits * M * N + (int64_t)blockIdx.y * M + m] = asum[e];
+                        else
+                            p.colsum_a[m] = p.accumulate ? p.colsum_a[m] + asum[e] : asum[e];
+                    }
+                }
+            }
+        }
+    }
+
+    // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool partial = p.splits > 1;
+    float* out = partial ? p.splitk_ws + (int64_t)blockIdx.y * M * N : p.C;
+    const int64_t ldo = partial ? N : p.ldc;
+    const bool has_mask = !partial && p.mask, has_add = !partial && p.addend;
+    const bool has_acc = !partial && p.accumulate;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            const int rbase = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+            const bool col_ok = col < N;
+            const float bias = (!partial && p.bias && col_ok) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {     // 8 rows at a time: aux operands fetched as a batch
+                float mk[8], ad[8], cc[8];
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = half * 8 + r8;
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    const bool ok = col_ok && row < M;
+                    mk[r8] = (has_mask && ok) ? p.mask[(int64_t)row * p.ldmask + col] : 1.f;
+                    ad[r8] = (has_add && ok) ? p.addend[(int64_t)row * p.ldadd + col] : 0.f;
+                    cc[r8] = (has_acc && ok) ? p.C[(int64_t)row * p.ldc + col] : 0.f;
+                }
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = half * 8 + r8;
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (col_ok && row < M) {
+                        float v = acc[i][j][r];
+                        if (!partial) {
+                            v += bias;
+                            if (p.relu) v = fmaxf(v, 0.f);
+                            if (has_mask) v = mk[r8] > 0.f ? v : 0.f;
+                            if (has_add) v += p.add_scale * ad[r8];
+                            if (has_acc) v += cc[r8];
+                        }
+                        out[(int64_t)row * ldo + col] = v;
+                    }
+                }
+            }
+        }
+}
+
+int64_t gemm_h16_plan_splits(int M, int N, int K, int* splits)
+{
+    const int mt = (M + HBM - 1) / HBM, nt = (N + HBN - 1) / HBN;
+    const int ktiles = (K + HBK - 1) / HBK;
+    int s = 1;
+    // fill whole rounds of 256 CUs x H_OCC resident blocks, >= 8 K tiles (256 k) per split
+    const int tiles = mt * nt, slots = 256 * H_OCC;
+    if (tiles < 2 * slots) {
+        double best = 0.0;
+        const int smax = std::min(64, std::max(1, ktiles / 8));
+        for (int c = 1; c <= smax; ++c) {
+            const int blocks = tiles * c;
+            const int rounds = (blocks + slots - 1) / slots;
+            const double eff = (double)blocks / ((double)rounds * slots) - 0.002 * c;
+            if (eff > best + 1e-9) { best = eff; s = c; }
+        }
+    }
+    *splits = s;
+    return s > 1 ? (int64_t)s * M * (N + 1) : 0;
+}
+
+int launch_gemm_h16_tiles(const GemmArgs& a, hipStream_t stream)
+{
+    const int mt = (a.M + HBM - 1) / HBM, nt = (a.N + HBN - 1) / HBN;
+    dim3 grid(mt * nt, a.splits), block(256);
+    const size_t smem = sizeof(unsigned short) * 4 * HBM * HLD;     // 2 operands x 2 buffers = 40 KiB
+    void (*kern)(GemmArgs) = nullptr;
+    const bool bf = a.prec == 2;
+#define SCTC_H16_PICK(AKV, BKV)                                                              \
+    kern = bf ? gemm_h16_kernel<AKV, BKV, true> : gemm_h16_kernel<AKV, BKV, false>
+    if (a.a_kcontig && a.b_kcontig) SCTC_H16_PICK(true, true);
+    else if (a.a_kcontig && !a.b_kcontig) SCTC_H16_PICK(true, false);
+    else if (!a.a_kcontig && a.b_kcontig) SCTC_H16_PICK(false, true);
+    else SCTC_H16_PICK(false, false);
+#undef SCTC_H16_PICK
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, a);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+}  // namespace sctc

@@ -40,6 +40,8 @@ struct RecArgs {
     int32_t variant;        // 0: pick automatically; 1: force the one-workgroup-per-CU kernel;
                             // 2: two-chain kernel with the linear (not XCD-grouped) block map
     unsigned* debug;        // nullable: s_memtime stamps [2 wgs][16 steps][8] for steps 64..79
+    int32_t prec16;         // != 0: "fp16 activations" -- the 6..16-utterance kernel exchanges the state
+                            // and holds the weights in 16 bit (float16 forward, bfloat16 BPTT), fp32 accumulate
 };
 // [2 wgs][16 steps][8] s_memtime stamps of steps 64..79, then [512 workgroups][8] wall-clock
 // (100 MHz, global) stamps of step 70 for every workgroup

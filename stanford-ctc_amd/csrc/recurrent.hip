@@ -862,6 +862,188 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_m_kernel(RecArgs p)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// 16-bit-operand variant of the mid-batch kernel for the "fp16 activations" configuration
+// (BASELINE configs[4]; 6..16 utterances, e.g. cfg-5 with minibatch 8): the recurrent weights
+// and the exchanged state are rounded to 16 bit (float16 in the forward pass, bfloat16 in BPTT:
+// deltas need fp32's exponent range), products are exact and accumulate in fp32 on
+// v_mfma_f32_16x16x32_{f16,bf16}; the per-frame term `pre`, the clip / mask and the stored
+// results stay fp32.  Same one-hop sentinel exchange as above, but a state row is Hp x 2 bytes:
+// half the fabric traffic per poll (the limit of the fp32 kernel at 16 utterances) and half the
+// LDS staging; a chunk is 32 K values, the A fragments (8 halves per lane) live in registers.
+// NCH = ceil(H/32/4) chunks per wave.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+template <bool BF> struct Rec16;
+template <> struct Rec16<false> {
+    using V8 = h16x8;
+    static __device__ __forceinline__ unsigned short bits(float v)
+    {
+        const _Float16 h = (_Float16)v;
+        return __builtin_bit_cast(unsigned short, h);
+    }
+    static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Rec16<true> {
+    using V8 = b16x8;
+    static __device__ __forceinline__ unsigned short bits(float v)
+    {
+        const __bf16 h = (__bf16)v;
+        return __builtin_bit_cast(unsigned short, h);
+    }
+    static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <int NCH, bool BF>
+__global__ __launch_bounds__(256, 1) void brnn_recurrent_mh_kernel(RecArgs p)
+{
+    using R = Rec16<BF>;
+    using V8 = typename R::V8;
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x & 1, wg = blockIdx.x >> 1;
+    const int Hp = p.Hp, nch = Hp >> 5;                      // 32-wide K chunks
+    const int row0 = wg * 16;
+    const int uj = lane & 15, kq = lane >> 4;
+    const int base = nch >> 2, rem = nch & 3;
+    const int cnt = base + (wave < rem ? 1 : 0);
+    const int c_beg = wave * base + min(wave, rem);
+    const int xld = Hp + 8;                                  // LDS row stride (halves): conflict-free b128 reads
+    unsigned short* xs = reinterpret_cast<unsigned short*>(lds4);          // [16][xld]
+    float4* red = lds4 + ((size_t)16 * xld * 2 + 15) / 16;                 // [3][64]
+
+    // ---- stationary weights as A fragments: wf[u] = { Wop[row0 + uj][32c + 8kq + e] }_e, 16 bit
+    V8 wf[NCH];
+    {
+        const float* W = p.W[g];
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int c = c_beg + min(u, cnt - 1);
+            unsigned short hb[8];
+            if (!p.transpose) {
+                const float4 v0 = *reinterpret_cast<const float4*>(W + (int64_t)(row0 + uj) * p.ldw + 32 * c + 8 * kq);
+                const float4 v1 = *reinterpret_cast<const float4*>(W + (int64_t)(row0 + uj) * p.ldw + 32 * c + 8 * kq + 4);
+                hb[0] = R::bits(v0.x); hb[1] = R::bits(v0.y); hb[2] = R::bits(v0.z); hb[3] = R::bits(v0.w);
+                hb[4] = R::bits(v1.x); hb[5] = R::bits(v1.y); hb[6] = R::bits(v1.z); hb[7] = R::bits(v1.w);
+            } else {
+                const float* col = W + (int64_t)(32 * c + 8 * kq) * p.ldw + row0 + uj;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hb[e] = R::bits(col[(int64_t)e * p.ldw]);
+            }
+            u32x4 packed = {(unsigned)hb[0] | ((unsigned)hb[1] << 16), (unsigned)hb[2] | ((unsigned)hb[3] << 16),
+                            (unsigned)hb[4] | ((unsigned)hb[5] << 16), (unsigned)hb[6] | ((unsigned)hb[7] << 16)};
+            wf[u] = __builtin_bit_cast(V8, packed);
+        }
+    }
+    const bool desc = p.descending[g] != 0;
+    const float* pre = p.pre[g];
+    const float* act = p.act[g];
+    float* out = p.out[g];
+    const int64_t ld = p.ld;
+    const float hi = p.max_act > 0.f ? p.max_act : INFINITY;
+    unsigned* err = p.counters + 2;
+    // exchange rows of 16-bit values: [direction][xrow][Hp] halves inside the fp32-sized buffer
+    unsigned short* xg = reinterpret_cast<unsigned short*>(p.xbuf) + (size_t)g * p.n_xrows * Hp;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        xg, 0, (int)((size_t)p.n_xrows * Hp * 2), 0x00020000);
+    const int uT = uj < p.B ? p.T_b[uj] : 0;                 // lane's utterance (sorted, longest first)
+    const int n16 = Hp >> 3;                                 // 16-byte pieces per state row
+    constexpr int NQ = (NCH * 4 * 4 + 63) / 64;              // pieces per lane: ceil(Hp/8/64)
+
+    int xb_next = p.xbase[0], xb_cur = 0;
+    for (int j = 0; j < p.Tmax; ++j) {
+        const int xb_prev = xb_cur;
+        xb_cur = xb_next;
+        xb_next = p.xbase[min(j + 1, p.Tmax - 1)];
+        const int nb = __builtin_amdgcn_readfirstlane(__popcll(__ballot(j < uT && kq == 0)));   // active prefix
+        const bool active = j < uT;
+        const int t = desc ? uT - 1 - j : j;
+        const int64_t orow = active ? (int64_t)p.rowbase[t] + uj : 0;
+        float4 pre4 = make_float4(0.f, 0.f, 0.f, 0.f), act4 = pre4;
+        if (wave == 0 && active) {
+            pre4 = *reinterpret_cast<const float4*>(pre + orow * ld + row0 + 4 * kq);
+            if (act) act4 = *reinterpret_cast<const float4*>(act + orow * ld + row0 + 4 * kq);
+        }
+        f32x4 acc[2];
+        acc[0] = {0.f, 0.f, 0.f, 0.f};
+        acc[1] = {0.f, 0.f, 0.f, 0.f};
+        if (j > 0) {
+            // ---- stage the previous state: rows round-robin over the waves, re-read until complete
+            first_poll_delay(p.poll_delay);
+            for (int bb = wave; bb < nb; bb += 4) {
+                const unsigned rowoff = (unsigned)(xb_prev + bb) * (unsigned)Hp * 2u;
+                const unsigned long long t0 = wall_clock64();
+                unsigned spins = 0;
+                u32x4 v[NQ];
+                for (;;) {
+#pragma unroll
+                    for (int c = 0; c < NQ; ++c) {
+                        const int item = min(c * 64 + lane, n16 - 1);
+                        v[c] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (unsigned)item * 16u, rowoff, 16 /* sc1 */);
+                    }
+                    bool ok = true;
+#pragma unroll
+                    for (int c = 0; c < NQ; ++c)
+                        ok = ok && v[c][0] != XSENT && v[c][1] != XSENT && v[c][2] != XSENT && v[c][3] != XSENT;
+                    if (__all(ok)) break;
+                    if ((++spins & 255u) == 0) {
+                        if (spin_expired(err, t0, lane)) break;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NQ; ++c) {
+                    const int item = c * 64 + lane;
+                    if (item < n16)
+                        *reinterpret_cast<u32x4*>(xs + (size_t)bb * xld + 8 * item) = v[c];
+                }
+            }
+            __syncthreads();
+            // ---- products: B fragment of chunk c = { x[uj][32c + 8kq + e] }_e from LDS
+            const unsigned short* xrow = xs + (size_t)uj * xld + 8 * kq;
+#pragma unroll
+            for (int u = 0; u < NCH; ++u) {
+                if (u < NCH - 1 || cnt == NCH) {
+                    const V8 x = *reinterpret_cast<const V8*>(xrow + 32 * (c_beg + u));
+                    acc[u & 1] = R::mfma(wf[u], x, acc[u & 1]);
+                }
+            }
+            if (wave != 0) {
+                const f32x4 sres = acc[0] + acc[1];
+                red[(wave - 1) * 64 + lane] = make_float4(sres[0], sres[1], sres[2], sres[3]);
+            }
+            __syncthreads();
+        }
+        if (wave == 0 && active) {
+            float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j > 0) {
+                const float4 r1 = red[lane], r2 = red[64 + lane], r3 = red[128 + lane];
+                const f32x4 q = acc[0] + acc[1];
+                sv = make_float4((q[0] + r1.x) + (r2.x + r3.x), (q[1] + r1.y) + (r2.y + r3.y),
+                                 (q[2] + r1.z) + (r2.z + r3.z), (q[3] + r1.w) + (r2.w + r3.w));
+            }
+            const float4 o = step_result(pre4, sv, act4, act != nullptr, hi);
+            *reinterpret_cast<float4*>(out + orow * ld + row0 + 4 * kq) = o;
+            // publish the 16-bit state: write-through, self-validating (no flag, no drain)
+            const u32x2 ou = {(unsigned)R::bits(o.x) | ((unsigned)R::bits(o.y) << 16),
+                              (unsigned)R::bits(o.z) | ((unsigned)R::bits(o.w) << 16)};
+            __builtin_amdgcn_raw_buffer_store_b64(ou, xrsrc, (unsigned)(row0 + 4 * kq) * 2u,
+                                                  (unsigned)(xb_cur + uj) * (unsigned)Hp * 2u, 16 /* sc1 */);
+        }
+        // the next step's staging overwrites the state rows in LDS: every wave must be done reading
+        __syncthreads();
+    }
+}
+
 size_t recurrent_xbuf_floats(int Hp, int64_t max_xrows)
 {
     return (size_t)2 * (size_t)max_xrows * Hp;  // one chunk-major state copy per direction
@@ -930,6 +1112,28 @@ int launch_recurrent(const RecArgs& a_in, hipStream_t stream)
             SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL(sk, dim3(2 * nwg), dim3(256), smem, stream, a);
+            SCTC_HIP_TRY(hipGetLastError());
+            return SCTC_OK;
+        }
+    }
+    if (a.prec16 && a.B > 5 && a.B <= 16 && a.variant != 1) {
+        // "fp16 activations": 16-bit state exchange and weights (float16 forward, bfloat16 BPTT)
+        RecKernel hk = nullptr;
+        const bool bf = a.transpose != 0;
+        const int nch = a.Hp / 32;
+        switch ((nch + 3) / 4) {
+            case 4:  if (nch == 16) hk = bf ? brnn_recurrent_mh_kernel<4, true>  : brnn_recurrent_mh_kernel<4, false>;  break;  // H = 512
+            case 8:  if (nch == 32) hk = bf ? brnn_recurrent_mh_kernel<8, true>  : brnn_recurrent_mh_kernel<8, false>;  break;  // H = 1024
+            case 15: if (nch == 57) hk = bf ? brnn_recurrent_mh_kernel<15, true> : brnn_recurrent_mh_kernel<15, false>; break;  // H = 1824
+            case 16: if (nch == 64) hk = bf ? brnn_recurrent_mh_kernel<16, true> : brnn_recurrent_mh_kernel<16, false>; break;  // H = 2048
+            default: break;
+        }
+        const size_t smem = (((size_t)16 * (a.Hp + 8) * 2 + 15) / 16) * 16 + 3 * 64 * sizeof(float4);
+        if (hk && smem <= 160 * 1024) {
+            SCTC_HIP_TRY(hipMemsetAsync(a.xbuf, 0xFF, (size_t)2 * a.n_xrows * a.Hp * 2, stream));
+            SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(hk),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(hk, dim3(2 * nwg), dim3(256), smem, stream, a);
             SCTC_HIP_TRY(hipGetLastError());
             return SCTC_OK;
         }

@@ -31,7 +31,7 @@ class TensorStack(list):
 class NNet:
 
     def __init__(self, inputDim, outputDim, layerSize, numLayers, maxBatch,
-                 train=True, temporalLayer=-1, reg=0.0, maxUtts=1):
+                 train=True, temporalLayer=-1, reg=0.0, maxUtts=1, fp16=False):
         cm.cublas_init()                      # brnnet.py:13 (fails here without the library)
         self.outputDim = outputDim
         self.inputDim = inputDim
@@ -40,6 +40,9 @@ class NNet:
         self.layerSizes = [layerSize] * numLayers
         self.maxBatch = maxBatch
         self.maxUtts = maxUtts
+        # extension (BASELINE configs[4] "fp16 acts / fp32 alpha-beta"): 16-bit operands on the
+        # matrix cores, fp32 accumulation; False = the reference's fp32 arithmetic
+        self.fp16 = bool(fp16)
         self.train = train
         self.reg = reg
         self.regcost = 0.0
@@ -60,7 +63,8 @@ class NNet:
         return _sctc.BrnnConfig(self.inputDim, self.outputDim, self.layerSize, self.numLayers,
                                 self.temporalLayer, int(self.maxBatch) * int(self.maxUtts),
                                 int(self.maxUtts), float(self.maxAct) if self.maxAct else 0.0,
-                                float(self.reg), 1 if self.train else 0)
+                                float(self.reg), 1 if self.train else 0,
+                                _sctc.F16 if self.fp16 else _sctc.F32)
 
     def _allocate(self):
         torch = _sctc.require_gpu()

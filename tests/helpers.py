@@ -93,8 +93,9 @@ def _oracle_chunk(idx):
     """worker of oracle_parallel: the utterances `idx` of the inherited problem; returns their
     costs / skips and the SUM of their gradients (one pickled gradient per worker, not per
     utterance)"""
-    params, datas, labs, TL, max_act, want_grad = _ORACLE_CTX
+    params, datas, labs, TL, max_act, want_grad, mixed_rec = _ORACLE_CTX
     from oracle import brnn as obrnn
+    mixed = None if mixed_rec is None else obrnn.Mixed(rec=mixed_rec)
     from oracle import ctc as octc
     try:
         from threadpoolctl import threadpool_limits
@@ -107,9 +108,9 @@ def _oracle_chunk(idx):
         for i in idx:
             data = np.asarray(datas[i], dtype=np.float64)
             if want_grad:
-                c, g, s, _ = obrnn.cost_and_grad(params, data, labs[i], TL, max_act)
+                c, g, s, _ = obrnn.cost_and_grad(params, data, labs[i], TL, max_act, mixed=mixed)
             else:
-                logits, _ = obrnn.forward(params, data, TL, max_act)
+                logits, _ = obrnn.forward(params, data, TL, max_act, mixed)
                 c, _, s = octc.ctc_loss(np.asfortranarray(obrnn.softmax_cols(logits)),
                                         np.ascontiguousarray(labs[i], dtype=np.int32), 0)
                 g = None
@@ -134,16 +135,18 @@ def job_threads():
     return max(1, int(os.environ.get("SCTC_ORACLE_THREADS", "8")))
 
 
-def oracle_parallel(params, datas, labs, TL, max_act=20.0, want_grad=True, procs=None):
+def oracle_parallel(params, datas, labs, TL, max_act=20.0, want_grad=True, procs=None,
+                    mixed_rec=None):
     """the float64 oracle over a list of utterances in forked worker processes (a few BLAS
     threads each): the full-size configurations take seconds instead of minutes on the GPU
-    box's host.  Returns (costs, summed gradient dict or None, skips)."""
+    box's host.  Returns (costs, summed gradient dict or None, skips).  mixed_rec: None = exact
+    float64; True / False = oracle.brnn.Mixed(rec=...) (the 16-bit-operand numerics)."""
     global _ORACLE_CTX
     import multiprocessing as mp
     import os
     n = len(datas)
     procs = procs or max(1, min(n, 16, (os.cpu_count() or 8) // job_threads()))
-    _ORACLE_CTX = (params, datas, labs, TL, max_act, want_grad)
+    _ORACLE_CTX = (params, datas, labs, TL, max_act, want_grad, mixed_rec)
     chunks = [list(range(k, n, procs)) for k in range(procs)]
     try:
         if procs == 1:

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(sctc):
     for n in names:
         assert hasattr(L, n), "libsctc_hip.so does not export %s" % n
     assert sorted(sctc.PROTOTYPES) == names, "ctypes prototypes out of sync with include/sctc.h"
-    assert L.sctc_abi_version() == 1
+    assert L.sctc_abi_version() == 2        # v2: sctc_brnn_config.operand_dtype, gemm_h16, *_reg
 
 
 def test_struct_mirrors_match_the_header(sctc, tmp_path):
@@ -46,13 +46,13 @@ def test_struct_mirrors_match_the_header(sctc, tmp_path):
         '#include <stdio.h>\n#include <stddef.h>\n#include "sctc.h"\n'
         'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sctc_ctc_batch),'
         ' offsetof(sctc_ctc_batch, rowbase_dev), sizeof(sctc_brnn_config),'
-        ' offsetof(sctc_brnn_config, train), sizeof(sctc_tensor_info), sizeof(sctc_brnn_sizes),'
+        ' offsetof(sctc_brnn_config, operand_dtype), sizeof(sctc_tensor_info), sizeof(sctc_brnn_sizes),'
         ' sizeof(sctc_minibatch), offsetof(sctc_minibatch, U_b)); return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(sctc.CtcBatch), sctc.CtcBatch.rowbase_dev.offset,
-            ctypes.sizeof(sctc.BrnnConfig), sctc.BrnnConfig.train.offset,
+            ctypes.sizeof(sctc.BrnnConfig), sctc.BrnnConfig.operand_dtype.offset,
             ctypes.sizeof(sctc.TensorInfo), ctypes.sizeof(sctc.BrnnSizes),
             ctypes.sizeof(sctc.Minibatch), sctc.Minibatch.U_b.offset]
     assert got == want

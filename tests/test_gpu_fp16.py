@@ -1,0 +1,181 @@
+"""The "fp16 activations" configuration (BASELINE configs[4]: "fp16 acts / fp32 alpha-beta",
+SURVEY 8(d) cfg-5; NNet(..., fp16=True) / sctc_brnn_config.operand_dtype = SCTC_F16).
+
+Numerics under test: the operands of every time-batched contraction (brnnet.py:140,196,204,
+227-230) and of the 6..16-utterance recurrent step (:148-152,215-224) are rounded to 16 bit --
+float16 in the forward pass, bfloat16 in the backward pass -- products exact, fp32 accumulation;
+master weights, stored activations, softmax, CTC (float64 lattices) unchanged.
+
+Two oracles: (i) oracle.brnn.Mixed restates exactly these roundings in float64 -- the GPU must
+agree with it to fp32-accumulation accuracy (cost 1e-4, gradients 2e-3: a value that sits on a
+16-bit rounding boundary may round the other way after an fp32 sum); (ii) the exact float64
+oracle (the reference's arithmetic) -- the stated tolerance of the CONFIGURATION: cost 2e-3
+relative, gradients 5e-2 relative Frobenius norm (8 mantissa bits in the backward pass)."""
+import numpy as np
+import pytest
+
+from tests.helpers import load_net, oracle_parallel
+from tests.test_gpu_brnn import host_stack, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def print(*a):      # observed errors also go to gpurun_out/test_notes.txt
+    import builtins
+    import os
+    builtins.print(*a)
+    d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "test_notes.txt"), "a") as f:
+            builtins.print(*a, file=f)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import _sctc
+    from nnets import brnnet
+    from oracle import brnn as obrnn
+    return _sctc, brnnet, obrnn, torch
+
+
+def make_net16(brnnet, dims, params, maxUtts=1, maxBatch=None):
+    D, A, H, NL, TL, T = dims
+    net = brnnet.NNet(D, A, H, NL, maxBatch or T, temporalLayer=TL, maxUtts=maxUtts, fp16=True)
+    net.setParams(host_stack(params))
+    return net
+
+
+def grad_errs(net, g, NL):
+    out = {}
+    for i in range(NL + 1):
+        out["W%d" % (i + 1)] = rel(net.grad[i][0].copy_to_host(), g["W"][i])
+        out["b%d" % (i + 1)] = rel(net.grad[i][1].copy_to_host().reshape(-1), np.asarray(g["b"][i]).reshape(-1))
+    if g["Wf"] is not None:
+        out["Wf"] = rel(net.grad[NL + 1][0].copy_to_host(), g["Wf"])
+        out["Wb"] = rel(net.grad[NL + 2][0].copy_to_host(), g["Wb"])
+    return out
+
+
+def test_gemm_h16_all_layouts(mods):
+    """sctc_gemm_h16 in the four operand layouts, ragged sizes, float16 and bfloat16 operands,
+    against the float64 product of the ROUNDED operands (the only error left is fp32 summation)"""
+    _sctc, _, obrnn, torch = mods
+    L = _sctc.lib()
+    rs = np.random.RandomState(0)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    for (M, N, K) in ((200, 96, 64), (130, 260, 1824), (1000, 1824, 512), (64, 1824, 3000),
+                      (1824, 512, 777), (32, 32, 4), (128, 128, 32), (260, 132, 36)):
+        for akc in (1, 0):
+            for bkc in (1, 0):
+                if (akc and K % 4) or (not akc and M % 4) or (bkc and K % 4) or (not bkc and N % 4):
+                    continue
+                for dt, rnd in ((_sctc.F16, obrnn.round_f16), (_sctc.BF16, obrnn.round_bf16)):
+                    A = rs.randn(M, K).astype(np.float32)
+                    Bm = rs.randn(K, N).astype(np.float32)
+                    bias = rs.randn(N).astype(np.float32)
+                    a_dev = torch.from_numpy(np.ascontiguousarray(A if akc else A.T)).cuda()
+                    b_dev = torch.from_numpy(np.ascontiguousarray(Bm.T if bkc else Bm)).cuda()
+                    c_dev = torch.full((M, N), 7.0, dtype=torch.float32, device="cuda")
+                    bias_dev = torch.from_numpy(bias).cuda()
+                    rc = L.sctc_gemm_h16(a_dev.data_ptr(), a_dev.shape[1], akc, b_dev.data_ptr(),
+                                         b_dev.shape[1], bkc, c_dev.data_ptr(), N, M, N, K,
+                                         bias_dev.data_ptr(), 1, dt, ws.data_ptr(), ws.numel(), None)
+                    _sctc.check(rc, "gemm_h16")
+                    torch.cuda.synchronize()
+                    ref = np.maximum(rnd(A) @ rnd(Bm) + bias, 0.0)
+                    err = np.abs(c_dev.cpu().numpy() - ref).max() / np.abs(ref).max()
+                    assert err < 3e-6, (M, N, K, akc, bkc, dt, err)
+    with pytest.raises(ValueError):
+        _sctc.check(L.sctc_gemm_h16(a_dev.data_ptr(), 4, 1, b_dev.data_ptr(), 4, 1, c_dev.data_ptr(),
+                                    4, 4, 4, 4, None, 0, _sctc.F32, None, 0, None), "gemm_h16")
+
+
+@pytest.mark.parametrize("name", ["cfg5", "cfg3"])
+def test_fp16_scaled_fixture(mods, golden, name):
+    """the scaled cfg-5 / cfg-3 twins (weights, data, labels of the rnnetcpu golden fixture):
+    minibatch 1 (recurrent step in fp32) against both oracles"""
+    _, brnnet, obrnn, _ = mods
+    params, grads, dims, data, labels, cost = load_net(golden("brnn_cfg.npz"), name + "_")
+    D, A, H, NL, TL, T = dims
+    net = make_net16(brnnet, dims, params)
+    c, _, skip = net.costAndGrad(data, labels)
+    assert not skip
+    with np.errstate(all="ignore"):
+        c_m, g_m, s_m, _ = obrnn.cost_and_grad(params, data, labels, TL, 20.0, mixed=obrnn.Mixed(rec=False))
+    assert c == pytest.approx(c_m, rel=1e-4)
+    e_m = grad_errs(net, g_m, NL)
+    e_x = grad_errs(net, grads, NL)
+    print("fp16 %s: cost vs mixed %.1e vs exact %.1e; grads vs mixed %.1e vs exact %.1e"
+          % (name, abs(c - c_m) / c_m, abs(c - cost) / cost, max(e_m.values()), max(e_x.values())))
+    assert max(e_m.values()) < 2e-3, e_m
+    assert c == pytest.approx(cost, rel=2e-3)
+    assert max(e_x.values()) < 5e-2, e_x
+
+
+@pytest.mark.parametrize("H,B", [(512, 8), (512, 16), (1024, 6), (1824, 9), (2048, 12)])
+def test_fp16_recurrent_step_mid_batch(mods, H, B):
+    """6..16 utterances: the 16-bit recurrent kernel (brnn_recurrent_mh_kernel; float16 state and
+    weights forward, bfloat16 in BPTT), ragged minibatch, against the Mixed(rec=True) oracle"""
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(17 * H + B)
+    D, A, NL, TL = 32, 33, 2, 1
+    Ts = [int(t) for t in rs.randint(2, 30, size=B)]
+    Ts[0] = 30
+    Ts[-1] = 1
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 8)).astype(np.int32) for T in Ts]
+    net = make_net16(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
+    costs, _, skips = net.costAndGradBatch(datas, labs)
+    g1 = [net.grad[i][0].copy_to_host().copy() for i in range(NL + 3)]
+    net.costAndGradBatch(datas, labs)
+    for a, i in zip(g1, range(NL + 3)):
+        np.testing.assert_array_equal(a, net.grad[i][0].copy_to_host())       # run-to-run reproducible
+    with np.errstate(all="ignore"):
+        c_m, g_m, s_m, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL, mixed=obrnn.Mixed(rec=True))
+        c_x, g_x, s_x, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+    np.testing.assert_array_equal(skips, s_m)
+    ok = ~s_m
+    np.testing.assert_allclose(costs[ok], c_m[ok], rtol=1e-4)
+    e_m = grad_errs(net, g_m, NL)
+    e_x = grad_errs(net, g_x, NL)
+    print("fp16 rec H=%d B=%d: cost vs mixed %.1e vs exact %.1e; grads vs mixed %.1e vs exact %.1e"
+          % (H, B, np.max(np.abs(costs[ok] - c_m[ok]) / c_m[ok]), np.max(np.abs(costs[ok] - c_x[ok]) / c_x[ok]),
+             max(e_m.values()), max(e_x.values())))
+    assert max(e_m.values()) < 2e-3, e_m
+    np.testing.assert_allclose(costs[ok], c_x[ok], rtol=2e-3)
+    assert max(e_x.values()) < 5e-2, e_x
+
+
+def test_fp16_cfg5_full_size(mods):
+    """cfg-5 as specified: T=8000, 7x2048, U=800, fp16 operands.  Minibatch 1 (fp32 recurrent
+    step) and 8 (16-bit recurrent step): costs against the Mixed oracle's forward pass + CTC and
+    against the exact float64 oracle (stated 2e-3)"""
+    _, brnnet, obrnn, torch = mods
+    D, A, H, NL, TL, T, U = 615, 33, 2048, 7, 4, 8000, 800
+    rs = np.random.RandomState(5)
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    B = 8
+    datas = [rs.randn(D, T).astype(np.float32) for _ in range(B)]
+    labs = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
+    net = make_net16(brnnet, (D, A, H, NL, TL, T), params, maxUtts=B, maxBatch=T)
+    c1, _, s1 = net.costAndGradBatch([datas[2]], [labs[2]])
+    assert not s1.any()
+    c8, _, s8 = net.costAndGradBatch(datas, labs)
+    assert not s8.any()
+    g8 = [net.grad[i][0].copy_to_host() for i in range(NL + 3)]
+    assert all(np.isfinite(g).all() for g in g8)
+    sel = [2, 5]
+    cm1, _, _ = oracle_parallel(params, [datas[2]], [labs[2]], TL, want_grad=False, procs=1, mixed_rec=False)
+    cm8, _, _ = oracle_parallel(params, [datas[i] for i in sel], [labs[i] for i in sel], TL,
+                                want_grad=False, mixed_rec=True)
+    cx, _, _ = oracle_parallel(params, [datas[i] for i in sel], [labs[i] for i in sel], TL, want_grad=False)
+    print("fp16 cfg5: B=1 cost %.3f mixed %.3f (rel %.1e) exact %.3f (rel %.1e); B=8 vs mixed %.1e vs exact %.1e"
+          % (c1[0], cm1[0], abs(c1[0] - cm1[0]) / cm1[0], cx[0], abs(c1[0] - cx[0]) / cx[0],
+             np.max(np.abs(c8[sel] - cm8) / cm8), np.max(np.abs(c8[sel] - cx) / cx)))
+    assert c1[0] == pytest.approx(cm1[0], rel=1e-4)
+    np.testing.assert_allclose(c8[sel], cm8, rtol=1e-4)
+    assert c1[0] == pytest.approx(cx[0], rel=2e-3)
+    np.testing.assert_allclose(c8[sel], cx, rtol=2e-3)
