@@ -188,9 +188,22 @@ typedef struct sctc_minibatch {
 int sctc_brnn_cost_and_grad(sctc_brnn_t h, const sctc_minibatch* mb, int32_t flags,
                             double* cost_host, int32_t* skip_host, double* regcost_host,
                             void* stream);
-/* same, results stay on the device (no host sync): cost_dev double[B], skip_dev int32[B] */
+/* same, results stay on the device (no host sync): cost_dev double[B], skip_dev int32[B].
+ * The caller must follow up with sctc_brnn_check before trusting the results. */
 int sctc_brnn_cost_and_grad_async(sctc_brnn_t h, const sctc_minibatch* mb, int32_t flags,
                                   double* cost_dev, int32_t* skip_dev, void* stream);
+/* Data-parallel overlap ("bucket by layer and launch as each wgrad GEMM finishes",
+ * output layer first, brnnet.py:191-193): the hipEvent_t the engine records on the step's stream
+ * right after the gradient of parameter tensor `index` is final (a weight tensor's event covers
+ * its bias; NULL for bias indices), and hipStreamWaitEvent for a caller that only holds raw
+ * stream pointers -- a side stream waits for tensor i's event and starts its all-reduce while
+ * the backward pass continues. */
+void* sctc_brnn_grad_event(sctc_brnn_t h, int32_t index);
+int sctc_stream_wait_event(void* stream, void* event);
+/* synchronises `stream` and reports a failure of the asynchronous work queued on it:
+ * SCTC_ERR_TIMEOUT when a persistent recurrent kernel gave up waiting for its peers (results of
+ * that call are then meaningless), SCTC_OK otherwise */
+int sctc_brnn_check(sctc_brnn_t h, void* stream);
 
 /* NNet(train=False).costAndGrad(data) (brnnet.py:171-173): probs_dev float [sum T][output_dim],
  * caller order, each utterance the reference's (outputDim,T) F-order probs */

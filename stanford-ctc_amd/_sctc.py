@@ -75,6 +75,9 @@ PROTOTYPES = {
                                                c_f64p, c_i32p, c_f64p, vp]),
     "sctc_brnn_cost_and_grad_async": (ctypes.c_int, [vp, ctypes.POINTER(Minibatch),
                                                      ctypes.c_int32, vp, vp, vp]),
+    "sctc_brnn_check": (ctypes.c_int, [vp, vp]),
+    "sctc_brnn_grad_event": (vp, [vp, ctypes.c_int32]),
+    "sctc_stream_wait_event": (ctypes.c_int, [vp, vp]),
     "sctc_brnn_forward": (ctypes.c_int, [vp, ctypes.POINTER(Minibatch), vp, vp]),
     "sctc_brnn_set_profiling": (ctypes.c_int, [vp, ctypes.c_int32]),
     "sctc_brnn_debug_read": (ctypes.c_int, [vp, vp, ctypes.c_int32]),

@@ -76,6 +76,10 @@ struct sctc_brnn {
     int64_t npairs = 0;
     bool pairs_contig = false;
 
+    // recorded on the step's stream when the gradient of parameter tensor i (weights: together
+    // with their bias) is final -- data-parallel callers start that tensor's all-reduce then
+    std::vector<hipEvent_t> grad_ev;
+
     // profiling
     int profiling = 0;
     hipEvent_t ev[SCTC_N_PHASES + 1][2];
@@ -436,6 +440,7 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
             r.poll_delay = h->rec_poll_delay;
             r.debug = h->rec_debug_on ? h->rec_debug : nullptr;
             r.prec16 = h->cfg.operand_dtype == SCTC_F16;
+            r.T_host = h->Ts.data();
             SCTC_TRY(launch_recurrent(r, s));
             pt.begin(SCTC_PHASE_OTHER);
             // hActs[i] = hActsFor + hActsBack, brnnet.py:153
@@ -552,6 +557,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             gemm_plan_splits(g.M, g.N, g.K, &splits, g.prec);
             g.splits = splits;
             SCTC_TRY(launch_gemm_f32(g, s));
+            SCTC_HIP_TRY(hipEventRecord(h->grad_ev[weight_index(h, i)], s));
         }
         if (i == 0) break;
         pt.begin(SCTC_PHASE_BWD_GEMM);
@@ -606,6 +612,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             r.poll_delay = h->rec_poll_delay;
             r.debug = h->rec_debug_on ? h->rec_debug + REC_DEBUG_WORDS : nullptr;
             r.prec16 = h->cfg.operand_dtype == SCTC_F16;
+            r.T_host = h->Ts.data();
             SCTC_TRY(launch_recurrent(r, s));
             pt.begin(SCTC_PHASE_BWD_GEMM);
             // dwtf = deltasFor[:,1:T] . hActsFor[:,0:T-1]^T ; dwtb = deltasBack[:,0:T-1] . hActsBack[:,1:T]^T
@@ -644,6 +651,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
                 gemm_plan_splits(g.M, g.N, std::max(g.K, 1), &splits, g.prec);
                 g.splits = splits;
                 SCTC_TRY(launch_gemm_f32(g, s));
+                SCTC_HIP_TRY(hipEventRecord(h->grad_ev[k == 0 ? wf_index(h) : wb_index(h)], s));
             }
             // deltasOut = deltasFor + deltasBack, brnnet.py:233
             pt.begin(SCTC_PHASE_OTHER);
@@ -729,6 +737,13 @@ int sctc_brnn_create(const sctc_brnn_config* cfg, float* params_dev, float* grad
         delete h;
         return set_error(SCTC_ERR_HIP, "brnn_create: %s", hipGetErrorString(e));
     }
+    h->grad_ev.resize(h->tinfo.size(), nullptr);
+    for (size_t i = 0; i < h->tinfo.size(); ++i)
+        if (cfg->train && h->tinfo[i].kind != 1 &&
+            hipEventCreateWithFlags(&h->grad_ev[i], hipEventDisableTiming) != hipSuccess) {
+            delete h;
+            return set_error(SCTC_ERR_HIP, "brnn_create: hipEventCreate failed");
+        }
     const char* sm = getenv("SCTC_REC_SYNC");
     h->rec_sync_mode = sm ? atoi(sm) : 1;
     const char* rv = getenv("SCTC_REC_VARIANT");
@@ -750,6 +765,8 @@ int sctc_brnn_destroy(sctc_brnn_t h)
             (void)hipEventDestroy(h->ev[i][1]);
         }
     if (h->ctc_stage) ctc_free_stage(h->ctc_stage);
+    for (hipEvent_t e : h->grad_ev)
+        if (e) (void)hipEventDestroy(e);
     delete h;
     return SCTC_OK;
 }
@@ -775,6 +792,28 @@ int sctc_brnn_cost_and_grad_async(sctc_brnn_t h, const sctc_minibatch* mb, int32
         SCTC_HIP_TRY(hipMemcpyAsync(skip_dev, h->d_skip_out, sizeof(int32_t) * h->B,
                                     hipMemcpyDeviceToDevice, s));
     return SCTC_OK;
+}
+
+void* sctc_brnn_grad_event(sctc_brnn_t h, int32_t index)
+{
+    if (!h || index < 0 || index >= (int)h->grad_ev.size()) {
+        set_error(SCTC_ERR_ARG, "brnn_grad_event: bad index %d", index);
+        return nullptr;
+    }
+    return (void*)h->grad_ev[index];
+}
+
+int sctc_stream_wait_event(void* stream, void* event)
+{
+    SCTC_CHECK_ARG(event, "stream_wait_event: null event");
+    SCTC_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return SCTC_OK;
+}
+
+int sctc_brnn_check(sctc_brnn_t h, void* stream)
+{
+    SCTC_CHECK_ARG(h, "brnn_check: null handle");
+    return check_recurrent_error(h, (hipStream_t)stream);
 }
 
 int sctc_brnn_cost_and_grad(sctc_brnn_t h, const sctc_minibatch* mb, int32_t flags,

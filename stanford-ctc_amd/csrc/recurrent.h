@@ -40,6 +40,9 @@ struct RecArgs {
     int32_t variant;        // 0: pick automatically; 1: force the one-workgroup-per-CU kernel;
                             // 2: two-chain kernel with the linear (not XCD-grouped) block map
     unsigned* debug;        // nullable: s_memtime stamps [2 wgs][16 steps][8] for steps 64..79
+    int32_t b_off;          // rank of this launch's first utterance in the packed minibatch (minibatches of
+                            // more than 128 utterances run as several launches; T_b already points at it)
+    const int32_t* T_host;  // nullable: host copy of the full (sorted) T_b, used to shorten later launches
     int32_t prec16;         // != 0: "fp16 activations" -- the 6..16-utterance kernel exchanges the state
                             // and holds the weights in 16 bit (float16 forward, bfloat16 BPTT), fp32 accumulate
 };

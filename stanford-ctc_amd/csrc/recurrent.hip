@@ -31,6 +31,10 @@
 //
 // The K index inside a 16-chunk is permuted (k = 16c + 4*(lane>>4) + q for MFMA q)
 // identically for W and x, so both operands are 16-byte vector loads.
+#include <algorithm>
+#include <map>
+#include <mutex>
+
 #include "common.h"
 #include "recurrent.h"
 #include "xlane.h"
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
         for (int i = 0; i < NTW; ++i) {
             active[i] = j < uT[i];
             const int t = desc ? uT[i] - 1 - j : j;
-            orow[i] = active[i] ? (int64_t)p.rowbase[t] + ub[i] : 0;
+            orow[i] = active[i] ? (int64_t)p.rowbase[t] + p.b_off + ub[i] : 0;
             // exchange rows are indexed by STEP (not by frame): all rows of one 256-byte-aligned
             // block are written in the same step in both time orders.  Finished / empty slots
             // read exchange row 0 (valid memory, result discarded).
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
             rb_next = p.rowbase[min(max(tn, 0), p.Tmax - 1)];
             xb_next = p.xbase[jn];
         }
-        const int64_t orow = active ? (int64_t)rb + ub : 0;
+        const int64_t orow = active ? (int64_t)rb + p.b_off + ub : 0;
         const unsigned xrow = active ? (unsigned)xb_cur + (unsigned)ub : 0u;
         const unsigned prow = (active && j > 0) ? (unsigned)xb_prev + (unsigned)ub : 0u;
         const unsigned xin = prow * 64u + (unsigned)kq * 16u;
@@ -621,7 +625,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
             orow[b] = 0;
             if (b < nb) {
                 const int t = desc ? Tb[b] - 1 - j : j;
-                orow[b] = (int64_t)p.rowbase[t] + b;
+                orow[b] = (int64_t)p.rowbase[t] + p.b_off + b;
                 if (owner) {
                     pre2[b] = *reinterpret_cast<const float2*>(pre + orow[b] * ld + row0);
                     if (act) act2[b] = *reinterpret_cast<const float2*>(act + orow[b] * ld + row0);
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_m_kernel(RecArgs p)
         const int nb = __builtin_amdgcn_readfirstlane(__popcll(__ballot(j < uT && kq == 0)));   // active prefix
         const bool active = j < uT;
         const int t = desc ? uT - 1 - j : j;
-        const int64_t orow = active ? (int64_t)p.rowbase[t] + uj : 0;
+        const int64_t orow = active ? (int64_t)p.rowbase[t] + p.b_off + uj : 0;
         float4 pre4 = make_float4(0.f, 0.f, 0.f, 0.f), act4 = pre4;
         if (wave == 0 && active) {
             pre4 = *reinterpret_cast<const float4*>(pre + orow * ld + row0 + 4 * kq);
@@ -968,7 +972,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_mh_kernel(RecArgs p)
         const int nb = __builtin_amdgcn_readfirstlane(__popcll(__ballot(j < uT && kq == 0)));   // active prefix
         const bool active = j < uT;
         const int t = desc ? uT - 1 - j : j;
-        const int64_t orow = active ? (int64_t)p.rowbase[t] + uj : 0;
+        const int64_t orow = active ? (int64_t)p.rowbase[t] + p.b_off + uj : 0;
         float4 pre4 = make_float4(0.f, 0.f, 0.f, 0.f), act4 = pre4;
         if (wave == 0 && active) {
             pre4 = *reinterpret_cast<const float4*>(pre + orow * ld + row0 + 4 * kq);
@@ -1057,7 +1061,7 @@ int recurrent_supported(int Hp, int B, char* why, int why_len)
                  2 * (Hp / 16));
         return 0;
     }
-    if (B > 128) { snprintf(why, why_len, "minibatch %d > 128 utterances per launch", B); return 0; }
+    (void)B;   // any minibatch size: more than 128 utterances run as several launches
     return 1;
 }
 
@@ -1071,6 +1075,142 @@ static RecKernel pick_kernel(int nch_half)
         case 64: return brnn_recurrent_kernel<NTW, 64>;   // H = 2048
         default: return brnn_recurrent_kernel<NTW, 0>;
     }
+}
+
+// Persistent kernels spin on other workgroups: every workgroup of the grid must be resident at
+// once.  The dynamic-LDS attribute is set once per kernel (not per step) and the grid is checked
+// against the occupancy the runtime reports, so that a grid that cannot be co-resident (another
+// process on the device, CU masking, a profiler holding LDS) fails fast or falls back instead of
+// spinning into the 3 s timeout.
+static int prepare_kernel(RecKernel k, size_t smem, int grid, int cus, bool* fits)
+{
+    struct Info { size_t smem_set = 0; size_t occ_smem = (size_t)-1; int occ = 0; };
+    static std::mutex mu;
+    static std::map<const void*, Info> table;
+    std::lock_guard<std::mutex> lock(mu);
+    Info& in = table[reinterpret_cast<const void*>(k)];
+    if (in.smem_set < smem) {
+        SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        in.smem_set = smem;
+    }
+    if (in.occ_smem != smem) {
+        int n = 0;
+        SCTC_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), 256, smem));
+        in.occ = n;
+        in.occ_smem = smem;
+    }
+    *fits = (int64_t)in.occ * cus >= grid;
+    return SCTC_OK;
+}
+
+static int not_resident(const char* which, int grid, int cus)
+{
+    return set_error(SCTC_ERR_STATE, "recurrent kernel (%s): %d workgroups cannot be co-resident on "
+                     "%d compute units (occupancy query) -- is the device shared or CU-masked?",
+                     which, grid, cus);
+}
+
+static int launch_recurrent_one(const RecArgs& a, int cus, hipStream_t stream)
+{
+    const int nwg = a.Hp / 16;
+    const int ntiles = (a.B + 15) / 16;
+    bool fits = false;
+    SCTC_HIP_TRY(hipMemsetAsync(a.counters, 0, REC_COUNTER_WORDS * sizeof(unsigned), stream));
+    // measured at H=1824: 2.5 us per step for one utterance + ~1.2 us per further one (VALU FMAs),
+    // against 7.4 us for the flag/MFMA kernel: worth it up to 5 utterances
+    if (a.B <= 5 && a.variant != 1) {
+        RecKernel sk = nullptr;
+        const bool s4 = a.B <= 4;
+        switch (a.Hp / 32) {
+            case 16: sk = s4 ? brnn_recurrent_s_kernel<16, 4> : brnn_recurrent_s_kernel<16, 8>; break;   // H = 512
+            case 32: sk = s4 ? brnn_recurrent_s_kernel<32, 4> : brnn_recurrent_s_kernel<32, 8>; break;   // H = 1024
+            case 57: sk = s4 ? brnn_recurrent_s_kernel<57, 4> : brnn_recurrent_s_kernel<57, 8>; break;   // H = 1824
+            case 64: sk = s4 ? brnn_recurrent_s_kernel<64, 4> : brnn_recurrent_s_kernel<64, 8>; break;   // H = 2048
+            default: break;
+        }
+        if (sk) {
+            const size_t smem = sizeof(float) * 2 * (s4 ? 4 : 8) * a.Hp;
+            SCTC_TRY(prepare_kernel(sk, smem, 2 * nwg, cus, &fits));
+            if (!fits) return not_resident("1..5 utterances", 2 * nwg, cus);
+            // sentinel-fill the exchange rows (both directions)
+            SCTC_HIP_TRY(hipMemsetAsync(a.xbuf, 0xFF, (size_t)2 * a.n_xrows * a.Hp * sizeof(float), stream));
+            hipLaunchKernelGGL(sk, dim3(2 * nwg), dim3(256), smem, stream, a);
+            SCTC_HIP_TRY(hipGetLastError());
+            return SCTC_OK;
+        }
+    }
+    if (a.prec16 && a.B > 5 && a.B <= 16 && a.variant != 1) {
+        // "fp16 activations": 16-bit state exchange and weights (float16 forward, bfloat16 BPTT)
+        RecKernel hk = nullptr;
+        const bool bf = a.transpose != 0;
+        const int nch = a.Hp / 32;
+        switch ((nch + 3) / 4) {
+            case 4:  if (nch == 16) hk = bf ? brnn_recurrent_mh_kernel<4, true>  : brnn_recurrent_mh_kernel<4, false>;  break;  // H = 512
+            case 8:  if (nch == 32) hk = bf ? brnn_recurrent_mh_kernel<8, true>  : brnn_recurrent_mh_kernel<8, false>;  break;  // H = 1024
+            case 15: if (nch == 57) hk = bf ? brnn_recurrent_mh_kernel<15, true> : brnn_recurrent_mh_kernel<15, false>; break;  // H = 1824
+            case 16: if (nch == 64) hk = bf ? brnn_recurrent_mh_kernel<16, true> : brnn_recurrent_mh_kernel<16, false>; break;  // H = 2048
+            default: break;
+        }
+        const size_t smem = (((size_t)16 * (a.Hp + 8) * 2 + 15) / 16) * 16 + 3 * 64 * sizeof(float4);
+        if (hk && smem <= 160 * 1024) {
+            SCTC_TRY(prepare_kernel(hk, smem, 2 * nwg, cus, &fits));
+            if (!fits) return not_resident("6..16 utterances, 16-bit state", 2 * nwg, cus);
+            SCTC_HIP_TRY(hipMemsetAsync(a.xbuf, 0xFF, (size_t)2 * a.n_xrows * a.Hp * 2, stream));
+            hipLaunchKernelGGL(hk, dim3(2 * nwg), dim3(256), smem, stream, a);
+            SCTC_HIP_TRY(hipGetLastError());
+            return SCTC_OK;
+        }
+    }
+    if (a.B > 5 && a.B <= 16 && a.variant != 1) {
+        RecKernel mk = nullptr;
+        switch ((nwg + 3) / 4) {
+            case 8:  if (nwg == 32)  mk = brnn_recurrent_m_kernel<8>;  break;   // H = 512
+            case 16: if (nwg == 64)  mk = brnn_recurrent_m_kernel<16>; break;   // H = 1024
+            case 29: if (nwg == 114) mk = brnn_recurrent_m_kernel<29>; break;   // H = 1824
+            case 32: if (nwg == 128) mk = brnn_recurrent_m_kernel<32>; break;   // H = 2048
+            default: break;
+        }
+        const size_t smem = sizeof(float) * ((size_t)16 * (a.Hp + 4) + 3 * 256);
+        if (mk && smem <= 160 * 1024) {
+            SCTC_TRY(prepare_kernel(mk, smem, 2 * nwg, cus, &fits));
+            if (!fits) return not_resident("6..16 utterances", 2 * nwg, cus);
+            SCTC_HIP_TRY(hipMemsetAsync(a.xbuf, 0xFF, (size_t)2 * a.n_xrows * a.Hp * sizeof(float), stream));
+            hipLaunchKernelGGL(mk, dim3(2 * nwg), dim3(256), smem, stream, a);
+            SCTC_HIP_TRY(hipGetLastError());
+            return SCTC_OK;
+        }
+    }
+    if (ntiles == 2 && a.variant != 1 && 4 * nwg <= 2 * cus && (4 * nwg) % 8 == 0) {
+        // two chains per CU; NREG keeps the LDS share of the slab at <= 76 KiB per workgroup
+        RecKernel qk = nullptr;
+        int ncq = 0, nreg = 0;
+        switch (nwg) {
+            case 32:  qk = brnn_recurrent_q_kernel<8, 0>;   ncq = 8;  nreg = 0;  break;  // H = 512
+            case 64:  qk = brnn_recurrent_q_kernel<16, 0>;  ncq = 16; nreg = 0;  break;  // H = 1024
+            case 114: qk = brnn_recurrent_q_kernel<29, 10>; ncq = 29; nreg = 10; break;  // H = 1824
+            case 128: qk = brnn_recurrent_q_kernel<32, 13>; ncq = 32; nreg = 13; break;  // H = 2048
+            default: break;
+        }
+        if (qk) {
+            const size_t smem = sizeof(float4) * ((size_t)4 * (ncq - nreg) * 64 + 3 * 64);
+            SCTC_TRY(prepare_kernel(qk, smem, 4 * nwg, cus, &fits));
+            if (fits) {     // otherwise: the one-workgroup-per-CU kernel below
+                hipLaunchKernelGGL(qk, dim3(4 * nwg), dim3(256), smem, stream, a);
+                SCTC_HIP_TRY(hipGetLastError());
+                return SCTC_OK;
+            }
+        }
+    }
+    const int ntw = ntiles <= 2 ? 1 : (ntiles <= 4 ? 2 : 4);
+    const size_t smem = sizeof(float4) * ((size_t)nwg * 64 + 2 * ntw * 64);
+    RecKernel kern = ntw == 1 ? pick_kernel<1>(nwg / 2)
+                     : (ntw == 2 ? pick_kernel<2>(nwg / 2) : pick_kernel<4>(nwg / 2));
+    SCTC_TRY(prepare_kernel(kern, smem, 2 * nwg, cus, &fits));
+    if (!fits) return not_resident("flag kernel", 2 * nwg, cus);
+    hipLaunchKernelGGL(kern, dim3(2 * nwg), dim3(256), smem, stream, a);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
 }
 
 int launch_recurrent(const RecArgs& a_in, hipStream_t stream)
@@ -1091,100 +1231,17 @@ int launch_recurrent(const RecArgs& a_in, hipStream_t stream)
     if (2 * nwg > cus)
         return set_error(SCTC_ERR_ARG, "recurrent kernel: needs %d co-resident workgroups, device "
                          "has %d CUs", 2 * nwg, cus);
-    const int ntiles = (a.B + 15) / 16;
-    SCTC_HIP_TRY(hipMemsetAsync(a.counters, 0, REC_COUNTER_WORDS * sizeof(unsigned), stream));
-    // measured at H=1824: 2.5 us per step for one utterance + ~1.2 us per further one (VALU FMAs),
-    // against 7.4 us for the flag/MFMA kernel: worth it up to 5 utterances
-    if (a.B <= 5 && a.variant != 1) {
-        RecKernel sk = nullptr;
-        const bool s4 = a.B <= 4;
-        switch (a.Hp / 32) {
-            case 16: sk = s4 ? brnn_recurrent_s_kernel<16, 4> : brnn_recurrent_s_kernel<16, 8>; break;   // H = 512
-            case 32: sk = s4 ? brnn_recurrent_s_kernel<32, 4> : brnn_recurrent_s_kernel<32, 8>; break;   // H = 1024
-            case 57: sk = s4 ? brnn_recurrent_s_kernel<57, 4> : brnn_recurrent_s_kernel<57, 8>; break;   // H = 1824
-            case 64: sk = s4 ? brnn_recurrent_s_kernel<64, 4> : brnn_recurrent_s_kernel<64, 8>; break;   // H = 2048
-            default: break;
-        }
-        if (sk) {
-            // sentinel-fill the exchange rows (both directions)
-            SCTC_HIP_TRY(hipMemsetAsync(a.xbuf, 0xFF, (size_t)2 * a.n_xrows * a.Hp * sizeof(float), stream));
-            const size_t smem = sizeof(float) * 2 * (s4 ? 4 : 8) * a.Hp;
-            SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(sk, dim3(2 * nwg), dim3(256), smem, stream, a);
-            SCTC_HIP_TRY(hipGetLastError());
-            return SCTC_OK;
-        }
+    // utterances are independent: more than 128 run as consecutive launches of <= 128 (sorted by
+    // length, so a later launch covers no more steps than its first utterance has frames)
+    constexpr int MAXB = 128;
+    for (int b0 = 0; b0 < a_in.B; b0 += MAXB) {
+        RecArgs c = a;
+        c.b_off = a_in.b_off + b0;
+        c.T_b = a_in.T_b + b0;
+        c.B = std::min(MAXB, a_in.B - b0);
+        if (a_in.T_host) c.Tmax = std::min(a_in.Tmax, (int)a_in.T_host[b0]);
+        SCTC_TRY(launch_recurrent_one(c, cus, stream));
     }
-    if (a.prec16 && a.B > 5 && a.B <= 16 && a.variant != 1) {
-        // "fp16 activations": 16-bit state exchange and weights (float16 forward, bfloat16 BPTT)
-        RecKernel hk = nullptr;
-        const bool bf = a.transpose != 0;
-        const int nch = a.Hp / 32;
-        switch ((nch + 3) / 4) {
-            case 4:  if (nch == 16) hk = bf ? brnn_recurrent_mh_kernel<4, true>  : brnn_recurrent_mh_kernel<4, false>;  break;  // H = 512
-            case 8:  if (nch == 32) hk = bf ? brnn_recurrent_mh_kernel<8, true>  : brnn_recurrent_mh_kernel<8, false>;  break;  // H = 1024
-            case 15: if (nch == 57) hk = bf ? brnn_recurrent_mh_kernel<15, true> : brnn_recurrent_mh_kernel<15, false>; break;  // H = 1824
-            case 16: if (nch == 64) hk = bf ? brnn_recurrent_mh_kernel<16, true> : brnn_recurrent_mh_kernel<16, false>; break;  // H = 2048
-            default: break;
-        }
-        const size_t smem = (((size_t)16 * (a.Hp + 8) * 2 + 15) / 16) * 16 + 3 * 64 * sizeof(float4);
-        if (hk && smem <= 160 * 1024) {
-            SCTC_HIP_TRY(hipMemsetAsync(a.xbuf, 0xFF, (size_t)2 * a.n_xrows * a.Hp * 2, stream));
-            SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(hk),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(hk, dim3(2 * nwg), dim3(256), smem, stream, a);
-            SCTC_HIP_TRY(hipGetLastError());
-            return SCTC_OK;
-        }
-    }
-    if (a.B > 5 && a.B <= 16 && a.variant != 1) {
-        RecKernel mk = nullptr;
-        switch ((nwg + 3) / 4) {
-            case 8:  if (nwg == 32)  mk = brnn_recurrent_m_kernel<8>;  break;   // H = 512
-            case 16: if (nwg == 64)  mk = brnn_recurrent_m_kernel<16>; break;   // H = 1024
-            case 29: if (nwg == 114) mk = brnn_recurrent_m_kernel<29>; break;   // H = 1824
-            case 32: if (nwg == 128) mk = brnn_recurrent_m_kernel<32>; break;   // H = 2048
-            default: break;
-        }
-        const size_t smem = sizeof(float) * ((size_t)16 * (a.Hp + 4) + 3 * 256);
-        if (mk && smem <= 160 * 1024) {
-            SCTC_HIP_TRY(hipMemsetAsync(a.xbuf, 0xFF, (size_t)2 * a.n_xrows * a.Hp * sizeof(float), stream));
-            SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mk),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(mk, dim3(2 * nwg), dim3(256), smem, stream, a);
-            SCTC_HIP_TRY(hipGetLastError());
-            return SCTC_OK;
-        }
-    }
-    if (ntiles == 2 && a.variant != 1 && 4 * nwg <= 2 * cus && (4 * nwg) % 8 == 0) {
-        // two chains per CU; NREG keeps the LDS share of the slab at <= 76 KiB per workgroup
-        RecKernel qk = nullptr;
-        int ncq = 0, nreg = 0;
-        switch (nwg) {
-            case 32:  qk = brnn_recurrent_q_kernel<8, 0>;   ncq = 8;  nreg = 0;  break;  // H = 512
-            case 64:  qk = brnn_recurrent_q_kernel<16, 0>;  ncq = 16; nreg = 0;  break;  // H = 1024
-            case 114: qk = brnn_recurrent_q_kernel<29, 10>; ncq = 29; nreg = 10; break;  // H = 1824
-            case 128: qk = brnn_recurrent_q_kernel<32, 13>; ncq = 32; nreg = 13; break;  // H = 2048
-            default: break;
-        }
-        if (qk) {
-            const size_t smem = sizeof(float4) * ((size_t)4 * (ncq - nreg) * 64 + 3 * 64);
-            SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(qk),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(qk, dim3(4 * nwg), dim3(256), smem, stream, a);
-            SCTC_HIP_TRY(hipGetLastError());
-            return SCTC_OK;
-        }
-    }
-    const int ntw = ntiles <= 2 ? 1 : (ntiles <= 4 ? 2 : 4);
-    const size_t smem = sizeof(float4) * ((size_t)nwg * 64 + 2 * ntw * 64);
-    RecKernel kern = ntw == 1 ? pick_kernel<1>(nwg / 2)
-                     : (ntw == 2 ? pick_kernel<2>(nwg / 2) : pick_kernel<4>(nwg / 2));
-    SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3(2 * nwg), dim3(256), smem, stream, a);
-    SCTC_HIP_TRY(hipGetLastError());
     return SCTC_OK;
 }
 

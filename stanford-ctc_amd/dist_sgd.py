@@ -55,6 +55,35 @@ def allreduce_flat(flat, side, bucket_elems=DEFAULT_BUCKET_ELEMS, group=None):
     return flat, side
 
 
+def allreduce_overlapped(net, side, group=None, side_stream=None):
+    """Sum-all-reduce net's flat gradient buffer bucket by bucket WHILE the backward pass queued
+    on the current stream is still running: a side stream waits for the event the
+    engine records when a layer's gradient is final (output layer first) and starts that layer's
+    all-reduce; RCCL moves the finished layers over xGMI while the GEMMs / BPTT of the earlier
+    layers compute.  `side` (small 1-D float64 device tensor, e.g. [n_valid, cost_sum, ...]) is
+    reduced last.  On return the CURRENT stream has been made to wait for all of it."""
+    import torch
+    import torch.distributed as dist
+    import _sctc
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    L = _sctc.lib()
+    flat = net.grad.flat
+    cur = torch.cuda.current_stream()
+    st = side_stream or torch.cuda.Stream()
+    works = []
+    with torch.cuda.stream(st):
+        for ev, start, end in net.gradBuckets():
+            _sctc.check(L.sctc_stream_wait_event(st.cuda_stream, ev), "stream_wait_event")
+            works.append(dist.all_reduce(flat[start:end], op=dist.ReduceOp.SUM, group=group,
+                                         async_op=True))
+        st.wait_stream(cur)                        # `side` is produced on the compute stream
+        works.append(dist.all_reduce(side, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        for w in works:
+            w.wait()                               # the side stream waits for the collectives
+    cur.wait_stream(st)
+
+
 class DataParallel(object):
     """Wraps an nnets.brnnet.NNet whose gradient stack lives in one flat device buffer."""
 
@@ -62,6 +91,7 @@ class DataParallel(object):
         self.net = net
         self.bucket_elems = bucket_elems
         self.group = group
+        self._side_stream = None
         self.n_valid = 0
         self.cost_sum = 0.0
         self.regcost = 0.0
@@ -79,8 +109,32 @@ class DataParallel(object):
                              0.0 if regcost_local is None else 1.0], dtype=torch.float64,
                             device=flat.device)
         allreduce_flat(flat, side, self.bucket_elems, self.group)
+        return self._finish(side)
+
+    def _finish(self, side):
         side = side.cpu()
         self.n_valid = int(round(side[0].item()))
         self.cost_sum = float(side[1].item())
         self.regcost = float(side[2].item() / side[3].item()) if side[3].item() > 0 else 0.0
         return 1.0 / self.n_valid if self.n_valid > 0 else 0.0
+
+    def allreduce_gradients_overlapped(self, cost_dev, skip_dev, regcost_local=None):
+        """after net.costAndGradBatchAsync (nothing synchronised yet): queues the per-layer
+        all-reduces behind the engine's gradient events on a side stream, builds the side message
+        [n_valid, cost_sum, regcost, has_regcost] ON THE DEVICE from the cost / skip arrays, and
+        only then synchronises.  cost_dev / skip_dev None = this rank's shard was empty (its
+        gradient buffer must already be zero)."""
+        import torch
+        flat = self.net.grad.flat
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        side = torch.zeros(4, dtype=torch.float64, device=flat.device)
+        if cost_dev is not None:
+            valid = skip_dev == 0
+            side[0] = valid.sum()
+            side[1] = torch.where(valid, cost_dev, torch.zeros_like(cost_dev)).sum()
+        if regcost_local is not None:       # 0-dim device tensor (NNet.regCostDev) or a number
+            side[2] = regcost_local
+            side[3] = 1.0
+        allreduce_overlapped(self.net, side, self.group, self._side_stream)
+        return self._finish(side)

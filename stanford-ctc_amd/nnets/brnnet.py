@@ -223,6 +223,68 @@ class NNet:
             self.regcost = regcost.value            # brnnet.py:178-183
         return cost, self.grad, skip.astype(bool)
 
+    def costAndGradBatchAsync(self, data_list, labels_list, accumulate=False, feats_dev=None,
+                              T_b=None, reg_in_grad=True):
+        """costAndGradBatch without a host sync: everything is queued on the current stream and
+        the per-utterance costs / skip flags stay on the device (float64 [B], int32 [B]).  Call
+        checkAsync() before trusting the results.  Used by the data-parallel trainer so that the
+        per-layer gradient all-reduces can be queued while the backward pass still runs."""
+        torch = _sctc.require_gpu()
+        if self._h is None:
+            raise RuntimeError("initParams() / fromFile() first")
+        if feats_dev is None:
+            T_b = [np.asarray(d).shape[1] for d in data_list]
+            feats_dev = self._stage(data_list)
+        for T in T_b:
+            self.setViews(T)
+        mb, keep = self._minibatch(feats_dev, T_b, labels_list)
+        B = len(T_b)
+        cost_dev = torch.empty(B, dtype=torch.float64, device="cuda")
+        skip_dev = torch.empty(B, dtype=torch.int32, device="cuda")
+        flags = (_sctc.FLAG_ACCUMULATE if accumulate else 0) | \
+                (0 if reg_in_grad else _sctc.FLAG_NO_REG_GRAD)
+        rc = _sctc.lib().sctc_brnn_cost_and_grad_async(
+            self._h, ctypes.byref(mb), flags, cost_dev.data_ptr(), skip_dev.data_ptr(),
+            _sctc.current_stream_ptr())
+        _sctc.check(rc, "costAndGrad")
+        self._async_keep = (feats_dev, keep)      # host label arrays / features outlive the launches
+        return cost_dev, skip_dev
+
+    def checkAsync(self):
+        """synchronises the current stream; raises if a persistent kernel of the queued step timed out"""
+        _sctc.check(_sctc.lib().sctc_brnn_check(self._h, _sctc.current_stream_ptr()), "costAndGrad")
+
+    def gradBuckets(self):
+        """[(event, start, end)] over the flat gradient buffer in the order the backward pass
+        finishes them (output layer first, brnnet.py:191-193; the recurrent pair right after the
+        temporal layer's BPTT); `event` is the raw hipEvent_t recorded when [start, end) is final"""
+        L = _sctc.lib()
+        NL = self.numLayers
+        offs = [int(ti.offset) for ti in self._infos] + [int(self._grads.numel())]
+        out = []
+        for i in range(NL, -1, -1):
+            out.append((L.sctc_brnn_grad_event(self._h, 2 * i), offs[2 * i], offs[2 * i + 2]))
+            if i == self.temporalLayer:
+                for k in (2 * (NL + 1), 2 * (NL + 1) + 1):
+                    out.append((L.sctc_brnn_grad_event(self._h, k), offs[k], offs[k + 1]))
+        return out
+
+    def regCostDev(self):
+        """(reg/2) * sum ||w||^2 over the weight tensors (brnnet.py:178-183) for the CURRENT
+        parameters as a 0-dim float64 device tensor (no host sync)"""
+        torch = _sctc.require_gpu()
+        L = _sctc.lib()
+        if not hasattr(self, "_reg_ws"):
+            self._reg_ws = torch.empty(8192, dtype=torch.uint8, device="cuda")
+        mats = [ti for ti in self._infos if ti.kind != 1]
+        out = torch.zeros(len(mats), dtype=torch.float64, device="cuda")
+        for j, ti in enumerate(mats):
+            rows_p, ld = cm.padded_layout(ti.rows, ti.cols)
+            _sctc.check(L.sctc_sumsq(self._params.data_ptr() + 4 * int(ti.offset), rows_p * ld,
+                                     out.data_ptr() + 8 * j, self._reg_ws.data_ptr(),
+                                     self._reg_ws.numel(), _sctc.current_stream_ptr()), "regcost")
+        return 0.5 * float(self.reg) * out.sum()
+
     def costAndGrad(self, data, labels=None, sentence=None):
         T = data.shape[1]
         self.setViews(T)

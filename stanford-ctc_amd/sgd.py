@@ -186,6 +186,7 @@ class SGD:
         reg_late = 0.0 if reference_mode else float(m.reg)
         # w = w + mom*velocity (evaluate gradient at future point), sgd.py:91-93
         m.updateParams(mom, self.velocity)
+        cost_dev = skip_dev = regc = None
         try:
             if reference_mode:
                 k, data, labels = batch[0]
@@ -193,26 +194,33 @@ class SGD:
                 if m.reg > 0:
                     cost -= m.regcost        # bookkept below like the batched path
                 costs, skips = np.array([cost]), np.array([skip])
+            elif world > 1:
+                # nothing synchronises here: the step is queued, then the per-layer all-reduces
+                # are queued behind the engine's gradient events (dist_sgd.allreduce_overlapped)
+                if local:
+                    cost_dev, skip_dev = m.costAndGradBatchAsync([d for _, d, _ in local],
+                                                                 [l for _, _, l in local],
+                                                                 reg_in_grad=False)
+                    if m.reg > 0:
+                        regc = m.regCostDev()        # at the look-ahead point, like brnnet.py:178
+                else:
+                    m.grad.flat.zero_()
             elif local:
                 costs, grad, skips = m.costAndGradBatch([d for _, d, _ in local],
                                                         [l for _, _, l in local],
                                                         reg_in_grad=False)
-            else:
-                m.grad.flat.zero_()
-                costs, skips = np.zeros(0), np.zeros(0, dtype=bool)
         finally:
             # undo update: w = w - mom*velocity, sgd.py:97-100 (also when the engine raised)
             m.updateParams(-mom, self.velocity)
-        n_valid = int((~skips).sum())
-        cost_sum = float(np.sum(costs[~skips])) if n_valid else 0.0
         if world > 1:
-            if n_valid == 0:
-                m.grad.flat.zero_()     # stale gradients must not enter the all-reduce
-            self._dp.allreduce_gradients(n_valid, cost_sum,
-                                         m.regcost if (local and m.reg > 0) else None)
+            self._dp.allreduce_gradients_overlapped(cost_dev, skip_dev, regc)
+            m.checkAsync()
             n_valid, cost_sum = self._dp.n_valid, self._dp.cost_sum
             if m.reg > 0:
                 m.regcost = self._dp.regcost
+        else:
+            n_valid = int((~skips).sum())
+            cost_sum = float(np.sum(costs[~skips])) if n_valid else 0.0
         if n_valid == 0:
             for (k, d, l) in batch:
                 logging.info("SKIPPING: Key=%s, SeqLen=%d, NumFrames=%d." % (k, l.shape[0], d.shape[1]))

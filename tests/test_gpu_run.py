@@ -78,10 +78,12 @@ def test_train_resume_and_export(tmp_path):
     np.testing.assert_allclose(np.log(p).T, ark[keys[0]], rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("reg", [0.0, 0.02])
-def test_data_parallel_trainer_two_ranks(tmp_path, reg):
+@pytest.mark.parametrize("reg,backend", [(0.0, "gloo"), (0.02, "gloo"), (0.02, "nccl")])
+def test_data_parallel_trainer_two_ranks(tmp_path, reg, backend):
     """(reg > 0: the L2 term must enter the update exactly once whatever the number of ranks --
-    it is added after the all-reduce and the 1/n_valid scaling, never per rank)
+    it is added after the all-reduce and the 1/n_valid scaling, never per rank; backend nccl =
+    RCCL, one GPU per rank, runs wherever two devices are visible so that the driver's scaling
+    run is not the first time RCCL executes this path)
     runNNet under torch.distributed.run with 2 ranks (gloo, both on the one GPU of the box):
     every rank processes its share of each minibatch, gradients are all-reduced, rank 0 owns the
     run directory -- and the parameters after one epoch equal those of the single-process run
@@ -90,6 +92,8 @@ def test_data_parallel_trainer_two_ranks(tmp_path, reg):
     import sys
     import torch
     assert torch.cuda.is_available()
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank (%d visible)" % torch.cuda.device_count())
     import runNNet
     rs = np.random.RandomState(1)
     raw = img = 12
@@ -106,10 +110,11 @@ def test_data_parallel_trainer_two_ranks(tmp_path, reg):
     runNNet.run(common + ["--outputDir", str(single)])
     dp = tmp_path / "dp"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SCTC_DIST_BACKEND="gloo", PYTHONPATH=os.pathsep.join(
+    env = dict(os.environ, SCTC_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONPATH=os.pathsep.join(
         [root, os.path.join(root, "stanford-ctc_amd"), os.environ.get("PYTHONPATH", "")]))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(29517 + (1 if reg else 0)),
+           "--master-addr", "127.0.0.1", "--master-port", str(29517 + (1 if reg else 0) + (2 if backend == "nccl" else 0)),
            os.path.join(root, "stanford-ctc_amd", "runNNet.py")] + common + ["--outputDir", str(dp)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
@@ -125,3 +130,29 @@ def test_data_parallel_trainer_two_ranks(tmp_path, reg):
     np.testing.assert_allclose(cost_d, cost_s, rtol=1e-5)
     for (ws, bs), (wd, bd) in zip(stack_s, stack_d):
         np.testing.assert_allclose(wd, ws, rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_bench_two_ranks(backend):
+    """bench.py under torch.distributed.run with 2 ranks (the driver's SCALE launch line): the
+    overlapped per-layer all-reduce path end to end, on a reduced minibatch.  gloo: both ranks
+    share the one GPU of the box; nccl (RCCL): only where two devices are visible."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank (%d visible)" % torch.cuda.device_count())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCTC_BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29541" if backend == "gloo" else "29542",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "6",
+           "--no-side", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["frames_per_step"] == 2 * 6 * 1000
+    assert out["cost_check"]["rel_err"] < 1e-4
