@@ -471,3 +471,23 @@ def test_recurrent_large_minibatch(mods, H, B):
     np.testing.assert_array_equal(skips, skips_ref)
     np.testing.assert_allclose(costs[~skips_ref], costs_ref[~skips_ref], rtol=1e-4)
     check_grads(net, g_ref, NL)
+
+
+def test_recurrent_more_than_128_utterances(mods):
+    """minibatches beyond one launch's 128 utterances run as consecutive launches of the
+    persistent kernels (utterances are independent): 150 ragged utterances against the oracle"""
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(77)
+    D, A, H, NL, TL, B = 16, 12, 64, 2, 1, 150
+    Ts = [int(t) for t in rs.randint(1, 15, size=B)]
+    Ts[5] = 15
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 6)).astype(np.int32) for T in Ts]
+    with np.errstate(all="ignore"):
+        costs_ref, g_ref, skips_ref, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+    net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
+    costs, _, skips = net.costAndGradBatch(datas, labs)
+    np.testing.assert_array_equal(skips, skips_ref)
+    np.testing.assert_allclose(costs[~skips_ref], costs_ref[~skips_ref], rtol=1e-4)
+    check_grads(net, g_ref, NL)
