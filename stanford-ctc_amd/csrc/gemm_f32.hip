@@ -43,7 +43,12 @@ static constexpr int KQ = BK / 4;   // float4 per row of a K-contiguous operand 
 template <int SHAPE> struct TileCfg;
 template <> struct TileCfg<0> { static constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2, NT = 256, OCC = SCTC_GEMM_OCC; };
 template <> struct TileCfg<1> { static constexpr int BM = 128, BN = 96, WGM = 4, WGN = 1, NT = 256, OCC = SCTC_GEMM_OCC1; };
-static constexpr int N_SHAPES = 2;
+//   2: 64x128 and 3: 128x64, 2x2 waves of 32x64 / 64x32 -- the output layer's contractions, whose
+//      M (weight gradient) or N (forward) is the alphabet (33 -> 64 padded): a 128-wide tile there
+//      is 3/4 padding (the weight gradient of the output layer ran 0.56 ms for 3.9 GFLOP)
+template <> struct TileCfg<2> { static constexpr int BM = 64, BN = 128, WGM = 2, WGN = 2, NT = 256, OCC = 4; };
+template <> struct TileCfg<3> { static constexpr int BM = 128, BN = 64, WGM = 2, WGN = 2, NT = 256, OCC = 4; };
+static constexpr int N_SHAPES = 4;
 // LDS row stride (floats): rows + 4 for both staging patterns.  Row-contiguous operands are
 // written with ds_write_b128; K-contiguous ones are transposed on the way in, lane (r = l/4,
 // c = l%4) writing element (k = 4c + j, row r): with a stride of 4 mod 16 the 64 lanes of one
@@ -328,29 +333,40 @@ __global__ __launch_bounds__(TileCfg<SHAPE>::NT, TileCfg<SHAPE>::OCC) void gemm_
             const int col = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
             const int rbase = m0 + wm * (TM * 32) + i * 32 + 4 * (lane >> 5);
             const bool col_ok = col < N;
-            const float bias = (!partial && p.bias && col_ok) ? p.bias[col] : 0.f;
-            float mk[16], ad[16], cc[16];
+            const int colc = min(col, N - 1);
+            const float bias = (!partial && p.bias) ? p.bias[colc] : 0.f;
+            // two halves of 8 accumulator rows: 24 auxiliary values live at a time instead of 48
+            // (the full-tile version spilled ~70 registers to scratch in every variant)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                const bool ok = col_ok && row < M;
-                mk[r] = (has_mask && ok) ? p.mask[(int64_t)row * p.ldmask + col] : 1.f;
-                ad[r] = (has_add && ok) ? p.addend[(int64_t)row * p.ldadd + col] : 0.f;
-                cc[r] = (has_acc && ok) ? p.C[(int64_t)row * p.ldc + col] : 0.f;
-            }
+            for (int half = 0; half < 2; ++half) {
+                float mk[8], ad[8], cc[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (col_ok && row < M) {
-                    float v = acc[i][j][r];
-                    if (!partial) {
-                        v += bias;
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        if (has_mask) v = mk[r] > 0.f ? v : 0.f;
-                        if (has_add) v += p.add_scale * ad[r];
-                        if (has_acc) v += cc[r];
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = half * 8 + r8;
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    // unconditional loads from clamped addresses (a load behind a per-lane
+                    // condition becomes an exec-mask branch with spills around it); out-of-range
+                    // elements are never stored
+                    const int64_t rc = min(row, M - 1);
+                    mk[r8] = has_mask ? p.mask[rc * p.ldmask + colc] : 1.f;
+                    ad[r8] = has_add ? p.addend[rc * p.ldadd + colc] : 0.f;
+                    cc[r8] = has_acc ? p.C[rc * p.ldc + colc] : 0.f;
+                }
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = half * 8 + r8;
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (col_ok && row < M) {
+                        float v = acc[i][j][r];
+                        if (!partial) {
+                            v += bias;
+                            if (p.relu) v = fmaxf(v, 0.f);
+                            if (has_mask) v = mk[r8] > 0.f ? v : 0.f;
+                            if (has_add) v += p.add_scale * ad[r8];
+                            if (has_acc) v += cc[r8];
+                        }
+                        out[(int64_t)row * ldo + col] = v;
                     }
-                    out[(int64_t)row * ldo + col] = v;
                 }
             }
         }
@@ -380,6 +396,8 @@ struct ShapeInfo { int bm, bn, occ; double penalty; };
 static const ShapeInfo kShapes[N_SHAPES] = {
     {TileCfg<0>::BM, TileCfg<0>::BN, TileCfg<0>::OCC, 0.00},
     {TileCfg<1>::BM, TileCfg<1>::BN, TileCfg<1>::OCC, 0.02},   // smaller tiles must save at least this much padded work
+    {TileCfg<2>::BM, TileCfg<2>::BN, TileCfg<2>::OCC, 0.10},
+    {TileCfg<3>::BM, TileCfg<3>::BN, TileCfg<3>::OCC, 0.10},
 };
 
 // tile shape with the least padded (wasted) matrix-core work for an M x N output
@@ -467,6 +485,8 @@ int launch_gemm_f32(GemmArgs a, hipStream_t stream)
     } else {
         switch (gemm_pick_shape(a.M, a.N)) {
             case 1: SCTC_TRY(launch_tiles<1>(a, stream)); break;
+            case 2: SCTC_TRY(launch_tiles<2>(a, stream)); break;
+            case 3: SCTC_TRY(launch_tiles<3>(a, stream)); break;
             default: SCTC_TRY(launch_tiles<0>(a, stream)); break;
         }
     }

@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256, H_OCC) void gemm_h16_kernel(GemmArgs p)
             const int col = n0 + wn * 64 + j * 32 + (lane & 31);
             const int rbase = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
             const bool col_ok = col < N;
-            const float bias = (!partial && p.bias && col_ok) ? p.bias[col] : 0.f;
+            const int colc = min(col, N - 1);
+            const float bias = (!partial && p.bias) ? p.bias[colc] : 0.f;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {     // 8 rows at a time: aux operands fetched as a batch
                 float mk[8], ad[8], cc[8];
@@ -289,10 +290,13 @@ __global__ __launch_bounds__(256, H_OCC) void gemm_h16_kernel(GemmArgs p)
                 for (int r8 = 0; r8 < 8; ++r8) {
                     const int r = half * 8 + r8;
                     const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    const bool ok = col_ok && row < M;
-                    mk[r8] = (has_mask && ok) ? p.mask[(int64_t)row * p.ldmask + col] : 1.f;
-                    ad[r8] = (has_add && ok) ? p.addend[(int64_t)row * p.ldadd + col] : 0.f;
-                    cc[r8] = (has_acc && ok) ? p.C[(int64_t)row * p.ldc + col] : 0.f;
+                    // unconditional loads from clamped addresses (a load behind a per-lane
+                    // condition becomes an exec-mask branch with spills around it); out-of-range
+                    // elements are never stored
+                    const int64_t rc = min(row, M - 1);
+                    mk[r8] = has_mask ? p.mask[rc * p.ldmask + colc] : 1.f;
+                    ad[r8] = has_add ? p.addend[rc * p.ldadd + colc] : 0.f;
+                    cc[r8] = has_acc ? p.C[rc * p.ldc + colc] : 0.f;
                 }
 #pragma unroll
                 for (int r8 = 0; r8 < 8; ++r8) {

@@ -803,6 +803,8 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_m_kernel(RecArgs p)
         for (int q = 0; q < 4; ++q) acc[q] = {0.f, 0.f, 0.f, 0.f};
         if (j > 0) {
             // ---- stage the previous state: rows round-robin over the waves, re-read until complete
+            // (one row in flight per wave: requesting all rows of a wave at once was measured 10 %
+            // SLOWER at 8 utterances x 2048 units -- an early poll then re-reads twice the bytes)
             first_poll_delay(p.poll_delay);
             for (int bb = wave; bb < nb; bb += 4) {
                 const unsigned rowoff = (unsigned)(xb_prev + bb) * (unsigned)Hp * 4u;
@@ -982,33 +984,56 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_mh_kernel(RecArgs p)
         acc[0] = {0.f, 0.f, 0.f, 0.f};
         acc[1] = {0.f, 0.f, 0.f, 0.f};
         if (j > 0) {
-            // ---- stage the previous state: rows round-robin over the waves, re-read until complete
+            // ---- stage the previous state: rows round-robin over the waves (wave w: rows w, w+4,
+            // w+8, w+12), all rows of a wave in flight at once, incomplete ones re-read until
+            // complete (half-size rows: -3 % per step at 8 utterances; the fp32 kernel keeps one row
+            // in flight, where two were measured slower)
             first_poll_delay(p.poll_delay);
-            for (int bb = wave; bb < nb; bb += 4) {
-                const unsigned rowoff = (unsigned)(xb_prev + bb) * (unsigned)Hp * 2u;
+            {
+                constexpr int MR = 4;
+                u32x4 v[MR][NQ];
+                bool need[MR];
+#pragma unroll
+                for (int r = 0; r < MR; ++r) need[r] = wave + 4 * r < nb;     // wave-uniform
                 const unsigned long long t0 = wall_clock64();
                 unsigned spins = 0;
-                u32x4 v[NQ];
                 for (;;) {
 #pragma unroll
-                    for (int c = 0; c < NQ; ++c) {
-                        const int item = min(c * 64 + lane, n16 - 1);
-                        v[c] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (unsigned)item * 16u, rowoff, 16 /* sc1 */);
-                    }
-                    bool ok = true;
+                    for (int r = 0; r < MR; ++r) {
+                        if (need[r]) {
+                            const unsigned rowoff = (unsigned)(xb_prev + wave + 4 * r) * (unsigned)Hp * 2u;
 #pragma unroll
-                    for (int c = 0; c < NQ; ++c)
-                        ok = ok && v[c][0] != XSENT && v[c][1] != XSENT && v[c][2] != XSENT && v[c][3] != XSENT;
-                    if (__all(ok)) break;
+                            for (int c = 0; c < NQ; ++c) {
+                                const int item = min(c * 64 + lane, n16 - 1);
+                                v[r][c] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (unsigned)item * 16u, rowoff, 16 /* sc1 */);
+                            }
+                        }
+                    }
+                    bool pending = false;
+#pragma unroll
+                    for (int r = 0; r < MR; ++r) {
+                        if (need[r]) {
+                            bool ok = true;
+#pragma unroll
+                            for (int c = 0; c < NQ; ++c)
+                                ok = ok && v[r][c][0] != XSENT && v[r][c][1] != XSENT && v[r][c][2] != XSENT && v[r][c][3] != XSENT;
+                            if (__all(ok)) {
+#pragma unroll
+                                for (int c = 0; c < NQ; ++c) {
+                                    const int item = c * 64 + lane;
+                                    if (item < n16)
+                                        *reinterpret_cast<u32x4*>(xs + (size_t)(wave + 4 * r) * xld + 8 * item) = v[r][c];
+                                }
+                                need[r] = false;
+                            } else {
+                                pending = true;
+                            }
+                        }
+                    }
+                    if (!pending) break;
                     if ((++spins & 255u) == 0) {
                         if (spin_expired(err, t0, lane)) break;
                     }
-                }
-#pragma unroll
-                for (int c = 0; c < NQ; ++c) {
-                    const int item = c * 64 + lane;
-                    if (item < n16)
-                        *reinterpret_cast<u32x4*>(xs + (size_t)bb * xld + 8 * item) = v[c];
                 }
             }
             __syncthreads();
@@ -1095,10 +1120,20 @@ static int prepare_kernel(RecKernel k, size_t smem, int grid, int cus, bool* fit
         in.smem_set = smem;
     }
     if (in.occ_smem != smem) {
-        int n = 0;
+        int n = 0, dev = 0, lds = 0;
         SCTC_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), 256, smem));
-        in.occ = n;
+        // The query under-reports kernels that use most of the 160 KiB LDS (measured: 1 block per CU
+        // for the two-chain kernel at 2 x 79 KiB, which does run two per CU), so the LDS budget
+        // itself is the second opinion: these kernels are LDS-limited by construction (their
+        // __launch_bounds__ guarantee the registers for 1 or 2 blocks per CU).
+        SCTC_HIP_TRY(hipGetDevice(&dev));
+        SCTC_HIP_TRY(hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev));
+        const int by_lds = smem ? (int)std::min<size_t>(2, (size_t)lds / smem) : 2;
+        in.occ = std::max(n, by_lds);
         in.occ_smem = smem;
+        if (getenv("SCTC_VERBOSE"))
+            fprintf(stderr, "sctc: recurrent kernel %p: %zu B LDS, occupancy query %d, LDS model %d blocks/CU\n",
+                    reinterpret_cast<const void*>(k), smem, n, by_lds);
     }
     *fits = (int64_t)in.occ * cus >= grid;
     return SCTC_OK;
