@@ -40,6 +40,7 @@ for p in (ROOT, os.path.join(ROOT, "stanford-ctc_amd")):
 CFG = dict(D=483, A=33, H=1824, NL=5, TL=3, T=1000, U=100, B=32)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32 matrix peak
 PEAK_HBM_GBPS = 8000.0
+PEAK_F16_MFMA_TFLOPS = 2500.0   # dense f16/bf16 MFMA peak
 PHASES = ["fwd_gemm", "fwd_rec", "ctc", "bwd_gemm", "bwd_rec", "other"]
 
 
@@ -351,6 +352,10 @@ def main():
                     for k in ("softmax_rows_kernel", "ctc_lattice_kernel", "ctc_grad_kernel"))
         if world == 1 and not args.no_side:
             side_measurements(out, net, feats, labels, Ts, rs, torch, B, T, D)
+            ctc_saturation(out, torch, A, T, U)
+            del net, feats, dev_bufs
+            torch.cuda.empty_cache()
+            cfg5_fp16(out, torch)
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
     if world > 1:
@@ -418,6 +423,92 @@ def side_measurements(out, net, feats, labels, Ts, rs, torch, B, T, D):
     out["ragged"] = {"value": sum(Tr) / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
                      "frames_per_step": sum(Tr),
                      "note": "T_b ~ U[T/2, T] sorted descending, U_b = T_b/10, same net, HBM-resident"}
+    # north_star "one utterance per stream": the recurrence keeps W stationary on ALL compute units
+    # for a whole pass, so two such launches cannot be co-resident -- utterances on separate
+    # streams serialise, and the stream variant is exactly this: one utterance per call
+    n1 = 4
+    dt = timed(lambda: [net.costAndGradBatch(None, [labels[i]], feats_dev=feats[i * T:(i + 1) * T], T_b=[T])
+                        for i in range(n1)], 2)
+    out["one_utterance_per_call"] = {
+        "value": n1 * T / dt, "unit": "frames/s", "ms_per_utterance": dt * 1e3 / n1,
+        "note": "the reference's mode (minibatch 1) and what one-utterance-per-stream degenerates to: "
+                "persistent weight-stationary launches of different streams cannot share the device"}
+
+
+def ctc_saturation(out, torch, A, T, U):
+    """roofline_ctc beside the headline minibatch: the CTC kernels alone at the batch that
+    saturates them (4096 utterances of the cfg-3 shape), float32 probabilities on the device"""
+    import ctc_fast
+    B = 4096
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    probs = torch.softmax(torch.randn(B * T, A, device="cuda", generator=g), dim=1)
+    rs = np.random.RandomState(7)
+    seqs = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
+    ctc_fast.ctc_loss_batch(probs, seqs, lengths=[T] * B)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctc_fast.ctc_loss_batch(probs, seqs, lengths=[T] * B)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    byts = B * (2 * 4 * A * T + 4 * U + 8)
+    out["roofline_ctc"]["saturating_batch"] = {
+        "utterances": B, "ms": dt * 1e3, "achieved": byts / dt / 1e9, "unit": "GB/s",
+        "frac": byts / dt / 1e9 / PEAK_HBM_GBPS,
+        "note": "ctc_lattice + ctc_grad (+ host wrapper) on 4096 utterances of T=%d U=%d; the float64 "
+                "lattice recursion is latency/compute-bound, not HBM-bound (DESIGN.md 4.3)" % (T, U)}
+
+
+def cfg5_fp16(out, torch):
+    """BASELINE configs[4] as specified: T=8000 A=33 7x2048 (temporalLayer 4, inputDim 615) U=800,
+    fp16 operands / fp32 accumulate / float64 CTC, minibatch 8 and 1 -- a side field, never `value`"""
+    from nnets import brnnet
+    import _sctc
+    D, A, H, NL, TL, T, U = 615, 33, 2048, 7, 4, 8000, 800
+    res = {}
+    for B in (8, 1):
+        np.random.seed(0)
+        net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B, fp16=True)
+        net.initParams()
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        feats = torch.randn(B * T, D, device="cuda", generator=g)
+        rs = np.random.RandomState(5)
+        labels = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
+        Ts = [T] * B
+        net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        L = _sctc.lib()
+        L.sctc_brnn_set_profiling(net._h, 1)
+        net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+        arr = (ctypes.c_float * len(PHASES))()
+        L.sctc_brnn_phase_ms(net._h, arr)
+        L.sctc_brnn_set_profiling(net._h, 0)
+        ph = dict(zip(PHASES, [float(v) for v in arr]))
+        tot, gm, rc = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        mb, keep = net._minibatch(feats, Ts, labels)
+        L.sctc_brnn_flops(net._h, ctypes.byref(mb), ctypes.byref(tot), ctypes.byref(gm), ctypes.byref(rc))
+        gemm_ms = ph["fwd_gemm"] + ph["bwd_gemm"]
+        res["minibatch_%d" % B] = {
+            "value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "phase_ms": ph,
+            "roofline_gemm": {"bound": "mfma", "kernel": "gemm_h16_kernel (f16 fwd / bf16 bwd operands, f32 accumulate)",
+                              "achieved": gm.value / (gemm_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS,
+                              "unit": "TFLOP/s", "frac": gm.value / (gemm_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                              "note": "operands stay fp32 in HBM and are rounded on their way into LDS: "
+                                      "the kernel is bound by operand traffic (L2), not by the matrix pipes"},
+            "us_per_recurrent_step": (ph["fwd_rec"] + ph["bwd_rec"]) * 1e3 / (2 * (T - 1)),
+            "ctc_ms": ph["ctc"]}
+        del net
+        torch.cuda.empty_cache()
+    out["cfg5_fp16"] = {"workload": "cfg-5: T=8000 A=33 7x2048 BRNN (temporalLayer 4, inputDim 615) U=800, "
+                                    "operand_dtype fp16 (float16 forward / bfloat16 backward operands, fp32 "
+                                    "accumulate, float64 CTC lattices), HBM-resident features",
+                        "dtype": "f16 operands / f32 accumulate", **res}
 
 
 if __name__ == "__main__":
