@@ -9,14 +9,22 @@
 // exactly "operands rounded to 16 bit, exact products, fp32 sums".
 //
 // The 16-bit MFMA runs 16x faster than the fp32 one (2.5 PFLOP/s dense): this kernel is bound
-// by operand traffic, not by the matrix pipes.  Tile 128x128x32, 256 threads = 2x2 waves of
-// 64x64 (2x2 MFMA tiles of 32x32x16), 3 blocks per CU so that one block's loads overlap the
-// others' MFMAs.  LDS image of both operands: [row][k] halves with a row stride of 40 halves
+// by operand traffic through the CU's vector memory path (64 B/clk), not by the matrix pipes.
+// Two tile shapes:
+//   BIG = 0: 128x128x32, 256 threads = 2x2 waves of 64x64 (2x2 MFMA tiles of 32x32x16), 3 blocks
+//            per CU so that one block's loads overlap the others' MFMAs;
+//   BIG = 1: 256x256x32, 512 threads = 2x4 waves of 128x64 (4x2 MFMA tiles), one block per CU:
+//            half the operand bytes per flop, chosen for large outputs.
+// LDS image of both operands: [row][k] halves with a row stride of 40 halves
 // (80 B): a fragment (lane l: row l&31, 8 consecutive k at 8*(l>>5)) is ONE ds_read_b128.
 //   K-contiguous operand  : float4 = 4 k of one row -> 4 halves -> one ds_write_b64;
 //   row-contiguous operand: every thread loads a 4(k) x 4(row) micro-tile (4 float4, lanes
 //     spread over 8 k-quads x 8 row-quads: 128-byte global segments), transposes it in
 //     registers and writes 4 x ds_write_b64 (conflict-free with this lane order).
+#include <algorithm>
+#include <mutex>
+#include <set>
+
 #include "common.h"
 #include "gemm_f32.h"
 
@@ -28,8 +36,11 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
 
-static constexpr int HBM = 128, HBN = 128, HBK = 32;
+static constexpr int HBK = 32;
 static constexpr int HLD = HBK + 8;      // LDS row stride in halves (80 B)
+template <int BIG> struct HTile;
+template <> struct HTile<0> { static constexpr int BM = 128, BN = 128, NT = 256, WGN = 2, TM = 2, TN = 2; };
+template <> struct HTile<1> { static constexpr int BM = 256, BN = 256, NT = 512, WGN = 4, TM = 4, TN = 2; };
 #ifndef SCTC_H16_OCC
 #define SCTC_H16_OCC 3
 #endif
@@ -63,9 +74,11 @@ template <> struct H16<true> {
     }
 };
 
-template <bool AK, bool BKC, bool BF>
-__global__ __launch_bounds__(256, H_OCC) void gemm_h16_kernel(GemmArgs p)
+template <bool AK, bool BKC, bool BF, int BIG>
+__global__ __launch_bounds__(HTile<BIG>::NT, BIG ? 2 : H_OCC) void gemm_h16_kernel(GemmArgs p)
 {
+    constexpr int HBM = HTile<BIG>::BM, HBN = HTile<BIG>::BN, NT = HTile<BIG>::NT;
+    constexpr int WGN = HTile<BIG>::WGN, TM = HTile<BIG>::TM, TN = HTile<BIG>::TN;
     using HT = H16<BF>;
     using V8 = typename HT::V8;
     using V4 = typename HT::V4;
@@ -75,7 +88,7 @@ __global__ __launch_bounds__(256, H_OCC) void gemm_h16_kernel(GemmArgs p)
     unsigned short* Bs = hsmem + 2 * OP;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int M = p.M, N = p.N, K = p.K;
     const int mt = (M + HBM - 1) / HBM, nt = (N + HBN - 1) / HBN;
     const int nblk = mt * nt;
@@ -91,11 +104,11 @@ __global__ __launch_bounds__(256, H_OCC) void gemm_h16_kernel(GemmArgs p)
     const int kt_beg = blockIdx.y * per;
     const int kt_end = min(ktiles, kt_beg + per);
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(256, H_OCC) void gemm_h16_kernel(GemmArgs p)
         if constexpr (AK) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                pa[q] = p.A + (int64_t)min(m0 + ((tid + 256 * q) >> 3), M - 1) * p.lda;
+                pa[q] = p.A + (int64_t)min(m0 + ((tid + NT * q) >> 3), M - 1) * p.lda;
         } else {
             pa[0] = p.A + min(m0 + 4 * (tid >> 3), (M - 1) & ~3);
 #pragma unroll
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(256, H_OCC) void gemm_h16_kernel(GemmArgs p)
         if constexpr (BKC) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                pb[q] = p.B + (int64_t)min(n0 + ((tid + 256 * q) >> 3), N - 1) * p.ldb;
+                pb[q] = p.B + (int64_t)min(n0 + ((tid + NT * q) >> 3), N - 1) * p.ldb;
         } else {
             pb[0] = p.B + min(n0 + 4 * (tid >> 3), (N - 1) & ~3);
 #pragma unroll
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(256, H_OCC) void gemm_h16_kernel(GemmArgs p)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (tail && kt * HBK + 4 * kq >= K) zero4(ra[q]);    // K % 4 == 0 here
-                    const int r = (tid + 256 * q) >> 3;
+                    const int r = (tid + NT * q) >> 3;
                     *reinterpret_cast<V4*>(a + r * HLD + 4 * kq) = HT::cvt(ra[q].x, ra[q].y, ra[q].z, ra[q].w);
                 }
             } else {
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(256, H_OCC) void gemm_h16_kernel(GemmArgs p)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (tail && kt * HBK + 4 * kq >= K) zero4(rb[q]);
-                    const int r = (tid + 256 * q) >> 3;
+                    const int r = (tid + NT * q) >> 3;
                     *reinterpret_cast<V4*>(b + r * HLD + 4 * kq) = HT::cvt(rb[q].x, rb[q].y, rb[q].z, rb[q].w);
                 }
             } else {
@@ -222,19 +235,19 @@ __global__ __launch_bounds__(256, H_OCC) void gemm_h16_kernel(GemmArgs p)
         for (int kt = kt_beg; kt < kt_end; ++kt) {
             const bool more = kt + 1 < kt_end;
             if (more) gload(kt + 1);          // in flight behind this tile's MFMAs
-            const unsigned short* a = As + buf * OP + (wm * 64 + li) * HLD + 8 * kg;
-            const unsigned short* b = Bs + buf * OP + (wn * 64 + li) * HLD + 8 * kg;
+            const unsigned short* a = As + buf * OP + (wm * (TM * 32) + li) * HLD + 8 * kg;
+            const unsigned short* b = Bs + buf * OP + (wn * (TN * 32) + li) * HLD + 8 * kg;
 #pragma unroll
             for (int ks = 0; ks < HBK / 16; ++ks) {
-                V8 af[2], bf[2];
+                V8 af[TM], bf[TN];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const V8*>(a + i * 32 * HLD + 16 * ks);
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const V8*>(a + i * 32 * HLD + 16 * ks);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const V8*>(b + j * 32 * HLD + 16 * ks);
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const V8*>(b + j * 32 * HLD + 16 * ks);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = HT::mfma(af[i], bf[j], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = HT::mfma(af[i], bf[j], acc[i][j]);
             }
             if (more) lstore(buf ^ 1, kt + 1);
             __syncthreads();
@@ -275,11 +288,11 @@ __global__ __launch_bounds__(256, H_OCC) void gemm_h16_kernel(GemmArgs p)
     const bool has_mask = !partial && p.mask, has_add = !partial && p.addend;
     const bool has_acc = !partial && p.accumulate;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            const int rbase = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
+            const int rbase = m0 + wm * (TM * 32) + i * 32 + 4 * (lane >> 5);
             const bool col_ok = col < N;
             const int colc = min(col, N - 1);
             const float bias = (!partial && p.bias) ? p.bias[colc] : 0.f;
@@ -318,13 +331,27 @@ __global__ __launch_bounds__(256, H_OCC) void gemm_h16_kernel(GemmArgs p)
         }
 }
 
+// the 256x256 tile when the output is large enough to give every CU whole tiles of it and its
+// padding does not cost more than it saves (H = 1824 = 7.1 x 256 pads 12 %)
+static int h16_pick_big(int M, int N)
+{
+    const char* force = getenv("SCTC_H16_TILE");     // diagnostics: 0 / 1
+    if (force) return atoi(force) ? 1 : 0;
+    auto padded = [](int v, int t) { return (double)((v + t - 1) / t * t) / v; };
+    const double small = padded(M, 128) * padded(N, 128), big = padded(M, 256) * padded(N, 256);
+    const int64_t tiles_big = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+    return (tiles_big >= 32 && big <= 1.06 * small) ? 1 : 0;
+}
+
 int64_t gemm_h16_plan_splits(int M, int N, int K, int* splits)
 {
-    const int mt = (M + HBM - 1) / HBM, nt = (N + HBN - 1) / HBN;
+    const int big = h16_pick_big(M, N);
+    const int bm = big ? 256 : 128, occ = big ? 1 : H_OCC;
+    const int mt = (M + bm - 1) / bm, nt = (N + bm - 1) / bm;
     const int ktiles = (K + HBK - 1) / HBK;
     int s = 1;
-    // fill whole rounds of 256 CUs x H_OCC resident blocks, >= 8 K tiles (256 k) per split
-    const int tiles = mt * nt, slots = 256 * H_OCC;
+    // fill whole rounds of 256 CUs x `occ` resident blocks, >= 8 K tiles (256 k) per split
+    const int tiles = mt * nt, slots = 256 * occ;
     if (tiles < 2 * slots) {
         double best = 0.0;
         const int smax = std::min(64, std::max(1, ktiles / 8));
@@ -339,23 +366,40 @@ int64_t gemm_h16_plan_splits(int M, int N, int K, int* splits)
     return s > 1 ? (int64_t)s * M * (N + 1) : 0;
 }
 
-int launch_gemm_h16_tiles(const GemmArgs& a, hipStream_t stream)
+template <int BIG>
+static int launch_h16(const GemmArgs& a, hipStream_t stream)
 {
-    const int mt = (a.M + HBM - 1) / HBM, nt = (a.N + HBN - 1) / HBN;
-    dim3 grid(mt * nt, a.splits), block(256);
-    const size_t smem = sizeof(unsigned short) * 4 * HBM * HLD;     // 2 operands x 2 buffers = 40 KiB
+    constexpr int BM = HTile<BIG>::BM, BN = HTile<BIG>::BN, NT = HTile<BIG>::NT;
+    const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
+    dim3 grid(mt * nt, a.splits), block(NT);
+    const size_t smem = sizeof(unsigned short) * 2 * (BM + BN) * HLD;     // 2 buffers x (A + B) tiles
     void (*kern)(GemmArgs) = nullptr;
     const bool bf = a.prec == 2;
 #define SCTC_H16_PICK(AKV, BKV)                                                              \
-    kern = bf ? gemm_h16_kernel<AKV, BKV, true> : gemm_h16_kernel<AKV, BKV, false>
+    kern = bf ? gemm_h16_kernel<AKV, BKV, true, BIG> : gemm_h16_kernel<AKV, BKV, false, BIG>
     if (a.a_kcontig && a.b_kcontig) SCTC_H16_PICK(true, true);
     else if (a.a_kcontig && !a.b_kcontig) SCTC_H16_PICK(true, false);
     else if (!a.a_kcontig && a.b_kcontig) SCTC_H16_PICK(false, true);
     else SCTC_H16_PICK(false, false);
 #undef SCTC_H16_PICK
+    if (smem > 64 * 1024) {
+        static std::mutex mu;
+        static std::set<const void*> done;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!done.count(reinterpret_cast<const void*>(kern))) {
+            SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            done.insert(reinterpret_cast<const void*>(kern));
+        }
+    }
     hipLaunchKernelGGL(kern, grid, block, smem, stream, a);
     SCTC_HIP_TRY(hipGetLastError());
     return SCTC_OK;
+}
+
+int launch_gemm_h16_tiles(const GemmArgs& a, hipStream_t stream)
+{
+    return h16_pick_big(a.M, a.N) ? launch_h16<1>(a, stream) : launch_h16<0>(a, stream);
 }
 
 }  // namespace sctc
