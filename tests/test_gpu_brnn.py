@@ -491,3 +491,41 @@ def test_recurrent_more_than_128_utterances(mods):
     np.testing.assert_array_equal(skips, skips_ref)
     np.testing.assert_allclose(costs[~skips_ref], costs_ref[~skips_ref], rtol=1e-4)
     check_grads(net, g_ref, NL)
+
+
+def test_async_entry_matches_sync(mods):
+    """sctc_brnn_cost_and_grad_async + sctc_brnn_check (the data-parallel trainer's entry): same
+    costs, skip flags and bit-identical gradients as the synchronous call; the gradient-ready
+    events cover the flat buffer exactly once in backward order (output layer first)"""
+    _, brnnet, obrnn, torch = mods
+    rs = np.random.RandomState(21)
+    D, A, H, NL, TL = 21, 33, 64, 4, 2
+    Ts = [30, 12, 25, 7, 30, 18]
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 6)).astype(np.int32) for T in Ts]
+    labs[3] = np.array([4, 4, 4, 4, 4], dtype=np.int32)          # infeasible at T=7 -> skip
+    net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=len(Ts), reg=0.01)
+    costs, _, skips = net.costAndGradBatch(datas, labs, reg_in_grad=False)
+    g_sync = net.grad.flat.clone()
+    net.grad.flat.zero_()
+    cost_dev, skip_dev = net.costAndGradBatchAsync(datas, labs, reg_in_grad=False)
+    net.checkAsync()
+    np.testing.assert_array_equal(skip_dev.cpu().numpy().astype(bool), skips)
+    np.testing.assert_array_equal(cost_dev.cpu().numpy()[~skips], costs[~skips])
+    assert torch.equal(net.grad.flat, g_sync)
+    # without the L2 term in the gradient; with it the difference is reg * W on the weights only
+    net.costAndGradBatch(datas, labs, reg_in_grad=True)
+    diff = (net.grad.flat - g_sync).cpu().numpy()
+    want = 0.01 * net._params.cpu().numpy()
+    for lo, hi in net.noreg_ranges().reshape(-1, 2):
+        want[lo:hi] = 0.0                                           # biases carry no L2 term
+    np.testing.assert_allclose(diff, want, rtol=1e-4, atol=1e-6)
+    buckets = net.gradBuckets()
+    assert all(ev for ev, _, _ in buckets)
+    spans = sorted((s, e) for _, s, e in buckets)
+    assert spans[0][0] == 0 and spans[-1][1] == net.grad.flat.numel()
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))     # exact cover, no overlap
+    assert buckets[0][1] == int(net._infos[2 * NL].offset)          # output layer first (brnnet.py:191-193)
+    assert [s for _, s, _ in buckets].index(int(net._infos[2 * (NL + 1)].offset)) == NL - TL + 1   # Wf right after the temporal layer
+    assert net.regCostDev().item() == pytest.approx(net.regcost, rel=1e-9)
