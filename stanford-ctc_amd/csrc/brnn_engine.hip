@@ -51,6 +51,13 @@ struct sctc_brnn {
     float *Z, *hF, *hB;       // temporal layer: pre-activation, forward / backward states
     float *logits, *probs, *dlogits;
     float *dA, *dBuf, *dF, *dBk;  // deltas: ping-pong pair + recurrent pair
+    // 16-bit shadow copies (operand_dtype = SCTC_F16 only; nullptr otherwise): f = float16 (forward
+    // operands), b = bfloat16 (backward operands).  Written by the producer of the fp32 matrix.
+    std::vector<uint16_t*> act16f, act16b;      // [NL + 1], shadows of act[i]
+    uint16_t *hF16b = nullptr, *hB16b = nullptr, *dF16b = nullptr, *dBk16b = nullptr;
+    uint16_t *dlogits16 = nullptr, *dA16 = nullptr, *dBuf16 = nullptr;
+    uint16_t* W16f = nullptr;                   // float16 copy of the flat parameter buffer (same offsets)
+    std::vector<uint16_t*> WT16b;               // [NL + 1]: bfloat16 W^T of layer l, [inp_p][LD(outp)]
     int32_t *d_rowbase, *d_nact, *d_Ts, *d_src_row, *d_idx_lo, *d_idx_hi, *d_xbase;
     void* ctc_ws;
     size_t ctc_ws_bytes;
@@ -182,6 +189,38 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
         dBuf = f(F * LD(d.Hp));
         if (d.TL > 0) { dF = f(F * LD(d.Hp)); dBk = f(F * LD(d.Hp)); }
     }
+    // 16-bit shadows
+    const bool h16 = c->operand_dtype == SCTC_F16;
+    std::vector<uint16_t*> act16f(d.NL + 1, nullptr), act16b(d.NL + 1, nullptr), WT16b(d.NL + 1, nullptr);
+    uint16_t *hF16b = nullptr, *hB16b = nullptr, *dF16b = nullptr, *dBk16b = nullptr, *dlogits16 = nullptr,
+             *dA16 = nullptr, *dBuf16 = nullptr, *W16f = nullptr;
+    if (h16) {
+        auto hh = [&](int64_t n) { return ar.take<uint16_t>((size_t)n); };
+        int64_t pe = 0, pc = 0;
+        {
+            std::vector<sctc_tensor_info> t;
+            build_tensor_table(d, &t, &pe, &pc);
+        }
+        W16f = hh(pe);
+        for (int i = 0; i <= d.NL; ++i) {
+            const int dim = i == 0 ? d.Dp : d.Hp;
+            act16f[i] = hh(F * LD(dim));
+            if (c->train) act16b[i] = hh(F * LD(dim));
+        }
+        if (c->train) {
+            for (int l = 1; l <= d.NL; ++l) {
+                const int outp = l == d.NL ? d.Ap : d.Hp;
+                WT16b[l] = hh((int64_t)d.Hp * LD(outp));
+            }
+            dlogits16 = hh(F * LD(d.Ap));
+            dA16 = hh(F * LD(d.Hp));
+            dBuf16 = hh(F * LD(d.Hp));
+            if (d.TL > 0) {
+                hF16b = hh(F * LD(d.Hp)); hB16b = hh(F * LD(d.Hp));
+                dF16b = hh(F * LD(d.Hp)); dBk16b = hh(F * LD(d.Hp));
+            }
+        }
+    }
     int32_t* d_rowbase = ar.take<int32_t>(F);
     int32_t* d_nact = ar.take<int32_t>(F);
     int32_t* d_Ts = ar.take<int32_t>(Bm);
@@ -235,6 +274,9 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
         h->ctc_ws = ctc_ws; h->ctc_ws_bytes = ctc_bytes;
         h->splitk_ws = splitk_ws; h->splitk_floats = sk;
         h->xbuf = xbuf; h->counters = counters; h->rec_debug = rec_debug;
+        h->act16f = act16f; h->act16b = act16b; h->WT16b = WT16b; h->W16f = W16f;
+        h->hF16b = hF16b; h->hB16b = hB16b; h->dF16b = dF16b; h->dBk16b = dBk16b;
+        h->dlogits16 = dlogits16; h->dA16 = dA16; h->dBuf16 = dBuf16;
         h->d_cost = d_cost; h->d_skip = d_skip; h->d_cost_out = d_cost_out;
         h->d_skip_out = d_skip_out; h->d_sumsq = d_sumsq; h->sumsq_ws = sumsq_ws;
     }
@@ -385,7 +427,15 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
     const int64_t N = h->N;
     pt.begin(SCTC_PHASE_OTHER);
     // brnnet.py:136 hActs[0] <- data, here also the re-ordering into the packed layout
-    SCTC_TRY(launch_gather_rows(h->X0, LD(h->Dp), mb->feats_dev, h->D, h->d_src_row, N, h->D, s));
+    const bool h16 = h->cfg.operand_dtype == SCTC_F16;
+    if (h16) {
+        SCTC_TRY(launch_gather_rows16(h->X0, h->act16f[0], h->cfg.train ? h->act16b[0] : h->act16f[0], LD(h->Dp),
+                                      mb->feats_dev, h->D, h->d_src_row, N, h->D, s));
+        // parameters change between calls: their 16-bit copies are refreshed per call (35 M elements)
+        SCTC_TRY(launch_cvt16(h->params, h->W16f, nullptr, round_up(h->param_elems, 4), s));
+    } else {
+        SCTC_TRY(launch_gather_rows(h->X0, LD(h->Dp), mb->feats_dev, h->D, h->d_src_row, N, h->D, s));
+    }
     for (int i = 1; i <= h->NL + 1; ++i) {
         pt.begin(SCTC_PHASE_FWD_GEMM);
         const int l = i - 1;
@@ -407,7 +457,17 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
         g.C = dst;
         g.ldc = LD(outp);
         g.relu = (i <= h->NL && i != h->TL) ? 1 : 0;             // brnnet.py:155-157
-        g.prec = h->cfg.operand_dtype == SCTC_F16 ? 1 : 0;       // forward: float16 operands
+        g.prec = h16 ? 1 : 0;                                    // forward: float16 operands
+        if (h16) {
+            g.in16 = 1;
+            g.A = reinterpret_cast<const float*>(h->act16f[i - 1]);
+            g.B = reinterpret_cast<const float*>(h->W16f + wi.offset);
+            if (dst != h->Z && dst != h->logits) {               // a hidden layer's output: shadows
+                g.C16a = h->act16f[i];
+                g.C16b = h->cfg.train ? h->act16b[i] : nullptr;
+                g.ldc16 = LD(outp);
+            }
+        }
         maybe_split(h, g);
         SCTC_TRY(launch_gemm_f32(g, s));
         if (i == h->TL) {
@@ -444,7 +504,15 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
             SCTC_TRY(launch_recurrent(r, s));
             pt.begin(SCTC_PHASE_OTHER);
             // hActs[i] = hActsFor + hActsBack, brnnet.py:153
-            SCTC_TRY(launch_add(h->act[i], h->hF, h->hB, N * LD(h->Hp), s));
+            if (h16) {
+                SCTC_TRY(launch_add16(h->act[i], h->hF, h->hB, h->act16f[i], h->act16b[i], N * LD(h->Hp), s));
+                if (h->cfg.train) {   // B operands of the recurrent weight gradient
+                    SCTC_TRY(launch_cvt16(h->hF, nullptr, h->hF16b, N * LD(h->Hp), s));
+                    SCTC_TRY(launch_cvt16(h->hB, nullptr, h->hB16b, N * LD(h->Hp), s));
+                }
+            } else {
+                SCTC_TRY(launch_add(h->act[i], h->hF, h->hB, N * LD(h->Hp), s));
+            }
         }
     }
     pt.begin(SCTC_PHASE_CTC);
@@ -523,9 +591,20 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
     const int acc = (flags & SCTC_FLAG_ACCUMULATE) ? 1 : 0;
     const float reg = (flags & SCTC_FLAG_NO_REG_GRAD) ? 0.f : h->cfg.reg;
     const int bprec = h->cfg.operand_dtype == SCTC_F16 ? 2 : 0;   // backward: bfloat16 operands
+    const bool h16 = bprec != 0;
     const float* d_in = h->dlogits;
+    const uint16_t* d_in16 = h->dlogits16;
     int d_in_ld = LD(h->Ap);
     float* bufs[2] = {h->dA, h->dBuf};
+    uint16_t* bufs16[2] = {h->dA16, h->dBuf16};
+    if (h16) {
+        SCTC_TRY(launch_cvt16(h->dlogits, nullptr, h->dlogits16, N * LD(h->Ap), s));
+        for (int l = 1; l <= h->NL; ++l) {        // W^T as the K-contiguous B operand of the delta GEMMs
+            const sctc_tensor_info& wl = h->tinfo[weight_index(h, l)];
+            const int outp = l == h->NL ? h->Ap : h->Hp;
+            SCTC_TRY(launch_transpose_bf16(h->params + wl.offset, LD(h->Hp), h->WT16b[l], LD(outp), outp, h->Hp, s));
+        }
+    }
     int which = 0;
     for (int i = h->NL; i >= 0; --i) {          // brnnet.py:191-243
         pt.begin(SCTC_PHASE_BWD_GEMM);
@@ -553,6 +632,11 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             g.colsum_a = h->grads + h->tinfo[bias_index(h, i)].offset;
             g.splitk_ws = h->splitk_ws;
             g.prec = bprec;
+            if (h16) {
+                g.in16 = 1;
+                g.A = reinterpret_cast<const float*>(d_in16);
+                g.B = reinterpret_cast<const float*>(h->act16b[i]);
+            }
             int splits = 1;
             gemm_plan_splits(g.M, g.N, g.K, &splits, g.prec);
             g.splits = splits;
@@ -578,6 +662,15 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             g.ldc = LD(inp);
             if (i != h->TL) { g.mask = h->act[i]; g.ldmask = LD(h->Hp); }
             g.prec = bprec;
+            if (h16) {
+                g.in16 = 1;
+                g.A = reinterpret_cast<const float*>(d_in16);
+                g.B = reinterpret_cast<const float*>(h->WT16b[i]);   // B(k = out, n = in) = W^T[in][out]
+                g.ldb = LD(outp);
+                g.b_kcontig = 1;
+                g.C16b = bufs16[which];
+                g.ldc16 = LD(inp);
+            }
             maybe_split(h, g);
             SCTC_TRY(launch_gemm_f32(g, s));
         }
@@ -615,6 +708,10 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             r.T_host = h->Ts.data();
             SCTC_TRY(launch_recurrent(r, s));
             pt.begin(SCTC_PHASE_BWD_GEMM);
+            if (h16) {   // A operands of the recurrent weight gradient
+                SCTC_TRY(launch_cvt16(h->dF, nullptr, h->dF16b, N * LD(h->Hp), s));
+                SCTC_TRY(launch_cvt16(h->dBk, nullptr, h->dBk16b, N * LD(h->Hp), s));
+            }
             // dwtf = deltasFor[:,1:T] . hActsFor[:,0:T-1]^T ; dwtb = deltasBack[:,0:T-1] . hActsBack[:,1:T]^T
             // (brnnet.py:227-230) over the (lo = frame t, hi = frame t+1) row pairs of every utterance
             for (int k = 0; k < 2; ++k) {
@@ -626,10 +723,14 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
                 g.B = k == 0 ? h->hF : h->hB;
                 g.ldb = LD(h->Hp);
                 g.b_kcontig = 0;
+                const uint16_t* a16 = k == 0 ? h->dF16b : h->dBk16b;
+                const uint16_t* b16 = k == 0 ? h->hF16b : h->hB16b;
                 if (h->pairs_contig) {
                     const int64_t hi0 = h->idx_hi[0], lo0 = h->idx_lo[0];
                     g.A += (k == 0 ? hi0 : lo0) * LD(h->Hp);
                     g.B += (k == 0 ? lo0 : hi0) * LD(h->Hp);
+                    a16 += (k == 0 ? hi0 : lo0) * LD(h->Hp);
+                    b16 += (k == 0 ? lo0 : hi0) * LD(h->Hp);
                 } else {
                     g.idx_a = k == 0 ? h->d_idx_hi : h->d_idx_lo;
                     g.idx_b = k == 0 ? h->d_idx_lo : h->d_idx_hi;
@@ -647,6 +748,11 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
                 }
                 g.splitk_ws = h->splitk_ws;
                 g.prec = bprec;
+                if (h16) {
+                    g.in16 = 1;
+                    g.A = reinterpret_cast<const float*>(a16);
+                    g.B = reinterpret_cast<const float*>(b16);
+                }
                 int splits = 1;
                 gemm_plan_splits(g.M, g.N, std::max(g.K, 1), &splits, g.prec);
                 g.splits = splits;
@@ -655,9 +761,11 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             }
             // deltasOut = deltasFor + deltasBack, brnnet.py:233
             pt.begin(SCTC_PHASE_OTHER);
-            SCTC_TRY(launch_add(d_out, h->dF, h->dBk, N * LD(h->Hp), s));
+            if (h16) SCTC_TRY(launch_add16(d_out, h->dF, h->dBk, nullptr, bufs16[which], N * LD(h->Hp), s));
+            else SCTC_TRY(launch_add(d_out, h->dF, h->dBk, N * LD(h->Hp), s));
         }
         d_in = d_out;
+        d_in16 = bufs16[which];
         d_in_ld = LD(h->Hp);
         which ^= 1;
     }

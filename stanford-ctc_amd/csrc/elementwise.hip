@@ -45,6 +45,77 @@ __global__ __launch_bounds__(256) void add_kernel(float4* __restrict__ out,
     }
 }
 
+// ---- 16-bit shadow copies for the mixed-precision GEMMs (operand_dtype = SCTC_F16): every
+// producer of an activation / delta matrix also writes it rounded to float16 (forward operands)
+// and / or bfloat16 (backward operands), so that the consuming GEMMs load half the bytes and
+// convert nothing.  Round-to-nearest-even, the same rounding the GEMM applies on the fly.
+__device__ __forceinline__ unsigned short to_f16(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
+__device__ __forceinline__ unsigned short to_bf16(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+
+// dst16a (float16, nullable) / dst16b (bfloat16, nullable) <- src, n4 float4 groups, same layout
+__global__ __launch_bounds__(256) void cvt16_kernel(const float4* __restrict__ src, ushort4* __restrict__ dst16a,
+                                                    ushort4* __restrict__ dst16b, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = src[i];
+        if (dst16a) dst16a[i] = make_ushort4(to_f16(v.x), to_f16(v.y), to_f16(v.z), to_f16(v.w));
+        if (dst16b) dst16b[i] = make_ushort4(to_bf16(v.x), to_bf16(v.y), to_bf16(v.z), to_bf16(v.w));
+    }
+}
+
+// out = a + b (fp32) plus its 16-bit shadows
+__global__ __launch_bounds__(256) void add16_kernel(float4* __restrict__ out, const float4* __restrict__ a,
+                                                    const float4* __restrict__ b, ushort4* __restrict__ o16a,
+                                                    ushort4* __restrict__ o16b, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 x = a[i], y = b[i];
+        const float4 v = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        out[i] = v;
+        if (o16a) o16a[i] = make_ushort4(to_f16(v.x), to_f16(v.y), to_f16(v.z), to_f16(v.w));
+        if (o16b) o16b[i] = make_ushort4(to_bf16(v.x), to_bf16(v.y), to_bf16(v.z), to_bf16(v.w));
+    }
+}
+
+// bfloat16 transpose of a row-major fp32 matrix: dst[c][r] = bf16(src[r][c]), rows x cols (padded
+// sizes, multiples of 32), through a 32 x 33 LDS tile (W^T as the K-contiguous B operand of the
+// delta-propagation GEMM)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const float* __restrict__ src, int64_t lds_,
+                                                             unsigned short* __restrict__ dst, int64_t ldd,
+                                                             int rows, int cols)
+{
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < rows && c < cols) ? src[(int64_t)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < cols && r < rows) dst[(int64_t)c * ldd + r] = to_bf16(tile[tx][k]);
+    }
+}
+
+// gather with shadows: dst[r][0..ldd) = src[idx[r]][0..cols) (zero padded), fp32 + float16 + bfloat16
+__global__ __launch_bounds__(256) void gather_rows16_kernel(float* __restrict__ dst, unsigned short* __restrict__ d16a,
+                                                            unsigned short* __restrict__ d16b, int64_t ldd,
+                                                            const float* __restrict__ src, int64_t lds_,
+                                                            const int32_t* idx, int64_t rows, int cols)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* s = src + (int64_t)idx[r] * lds_;
+    for (int c = lane; c < ldd; c += 64) {
+        const float v = c < cols ? s[c] : 0.f;
+        dst[r * ldd + c] = v;
+        d16a[r * ldd + c] = to_f16(v);
+        d16b[r * ldd + c] = to_bf16(v);
+    }
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y,
                                                    const float* __restrict__ x, float alpha,
                                                    int64_t n)
@@ -200,6 +271,47 @@ int launch_add(float* out, const float* a, const float* b, int64_t n, hipStream_
     SCTC_CHECK_ARG(n % 4 == 0, "add: element count must be a multiple of 4");
     hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, (float4*)out,
                        (const float4*)a, (const float4*)b, n / 4);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+int launch_cvt16(const float* src, uint16_t* dst_f16, uint16_t* dst_bf16, int64_t n, hipStream_t s)
+{
+    if (n <= 0 || (!dst_f16 && !dst_bf16)) return SCTC_OK;
+    SCTC_CHECK_ARG(n % 4 == 0, "cvt16: element count must be a multiple of 4");
+    hipLaunchKernelGGL(cvt16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, (const float4*)src,
+                       (ushort4*)dst_f16, (ushort4*)dst_bf16, n / 4);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+int launch_add16(float* out, const float* a, const float* b, uint16_t* o_f16, uint16_t* o_bf16, int64_t n,
+                 hipStream_t s)
+{
+    if (n <= 0) return SCTC_OK;
+    SCTC_CHECK_ARG(n % 4 == 0, "add: element count must be a multiple of 4");
+    hipLaunchKernelGGL(add16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, (float4*)out, (const float4*)a,
+                       (const float4*)b, (ushort4*)o_f16, (ushort4*)o_bf16, n / 4);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+int launch_transpose_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int rows, int cols,
+                          hipStream_t s)
+{
+    if (rows <= 0 || cols <= 0) return SCTC_OK;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, src,
+                       ld_src, dst, ld_dst, rows, cols);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+int launch_gather_rows16(float* dst, uint16_t* d_f16, uint16_t* d_bf16, int64_t ldd, const float* src,
+                         int64_t lds, const int32_t* idx, int64_t rows, int cols, hipStream_t s)
+{
+    if (rows <= 0) return SCTC_OK;
+    hipLaunchKernelGGL(gather_rows16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, dst, d_f16,
+                       d_bf16, ldd, src, lds, idx, rows, cols);
     SCTC_HIP_TRY(hipGetLastError());
     return SCTC_OK;
 }

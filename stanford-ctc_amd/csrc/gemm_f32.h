@@ -43,6 +43,16 @@ struct GemmArgs {
     // 1 = float16, 2 = bfloat16: both operands rounded to 16 bit on the way into LDS, fp32
     // accumulate (gemm_h16.hip; the "fp16 activations" configuration)
     int32_t prec;
+    // prec != 0 only.  in16: both operands are ALREADY 16-bit in memory (float16 for prec 1,
+    // bfloat16 for prec 2; `A` / `B` then point at 2-byte elements, lda / ldb count them): the
+    // shadow copies the producers below write.  K-contiguous 16-bit operands need K % 8 == 0.
+    int32_t in16;
+    // optional 16-bit shadow copies of the result, written by the epilogue next to C (same
+    // row stride ldc16 for both): C16a = float16, C16b = bfloat16 -- the operands of the GEMMs that
+    // consume C next, rounded once by their producer instead of by every consumer
+    uint16_t* C16a;
+    uint16_t* C16b;
+    int64_t ldc16;
 };
 
 // picks the split-K factor; returns the workspace floats needed (0 when splits == 1)

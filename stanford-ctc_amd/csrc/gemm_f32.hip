@@ -380,7 +380,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p)
         float v = 0.f;
         for (int z = 0; z < p.splits; ++z) v += p.splitk_ws[z * total + i];  // fixed order
         const int row = (int)(i / p.N), col = (int)(i % p.N);
-        p.C[(int64_t)row * p.ldc + col] = gemm_epilogue(p, v, row, col);
+        const float o = gemm_epilogue(p, v, row, col);
+        p.C[(int64_t)row * p.ldc + col] = o;
+        if (p.C16a) p.C16a[(int64_t)row * p.ldc16 + col] = __builtin_bit_cast(unsigned short, (_Float16)o);
+        if (p.C16b) p.C16b[(int64_t)row * p.ldc16 + col] = __builtin_bit_cast(unsigned short, (__bf16)o);
     }
     if (p.colsum_a && !p.a_kcontig) {
         const float* part = p.splitk_ws + (int64_t)p.splits * total;
@@ -473,6 +476,14 @@ int launch_gemm_f32(GemmArgs a, hipStream_t stream)
     SCTC_CHECK_ARG(a.lda % 4 == 0 && a.ldb % 4 == 0, "gemm: lda/ldb must be multiples of 4");
     SCTC_CHECK_ARG(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0,
                    "gemm: operands must be 16-byte aligned");
+    if (a.in16) {
+        SCTC_CHECK_ARG(a.prec != 0 && a.a_kcontig == a.b_kcontig && a.lda % 8 == 0 && a.ldb % 8 == 0 &&
+                           (!a.a_kcontig || a.K % 8 == 0),
+                       "gemm: 16-bit operands need prec != 0, equal operand layouts, lda/ldb % 8 == 0 "
+                       "and (K-contiguous) K % 8 == 0");
+    } else {
+        SCTC_CHECK_ARG((!a.C16a && !a.C16b) || a.prec != 0, "gemm: 16-bit shadow outputs need prec != 0");
+    }
     if (a.a_kcontig) SCTC_CHECK_ARG(a.K % 4 == 0, "gemm: K must be a multiple of 4 (A K-contig)");
     else SCTC_CHECK_ARG(a.M % 4 == 0, "gemm: M must be a multiple of 4 (A row-contig)");
     if (a.b_kcontig) SCTC_CHECK_ARG(a.K % 4 == 0, "gemm: K must be a multiple of 4 (B K-contig)");

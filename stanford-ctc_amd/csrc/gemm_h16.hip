@@ -1,29 +1,34 @@
 // Mixed-precision GEMM for the "fp16 activations" configuration (BASELINE configs[4], cfg-5):
 // the same contractions as gemm_f32.hip (brnnet.py:140 fwd, :196 wgrad, :204 dgrad,
-// :227-230 recurrent wgrad) with BOTH operands rounded to a 16-bit type on their way into
-// LDS and fp32 accumulation on the matrix cores:
+// :227-230 recurrent wgrad) with BOTH operands rounded to a 16-bit type and fp32 accumulation on
+// the matrix cores:
 //   prec 1: float16  (v_mfma_f32_32x32x16_f16)   -- forward pass (activations in [0, 20])
 //   prec 2: bfloat16 (v_mfma_f32_32x32x16_bf16)  -- backward pass (deltas need fp32's exponent range)
-// Master weights, activations, deltas and gradients stay fp32 in HBM; the rounding happens in
-// registers (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round-to-nearest-even), so the numerics are
-// exactly "operands rounded to 16 bit, exact products, fp32 sums".
+// Master weights, activations, deltas and gradients stay fp32 in HBM; the rounding is
+// round-to-nearest-even (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32), so the numerics are exactly
+// "operands rounded to 16 bit, exact products, fp32 sums".
 //
-// The 16-bit MFMA runs 16x faster than the fp32 one (2.5 PFLOP/s dense): this kernel is bound
-// by operand traffic through the CU's vector memory path (64 B/clk), not by the matrix pipes.
-// Two tile shapes:
-//   BIG = 0: 128x128x32, 256 threads = 2x2 waves of 64x64 (2x2 MFMA tiles of 32x32x16), 3 blocks
-//            per CU so that one block's loads overlap the others' MFMAs;
-//   BIG = 1: 256x256x32, 512 threads = 2x4 waves of 128x64 (4x2 MFMA tiles), one block per CU:
-//            half the operand bytes per flop, chosen for large outputs.
-// LDS image of both operands: [row][k] halves with a row stride of 40 halves
-// (80 B): a fragment (lane l: row l&31, 8 consecutive k at 8*(l>>5)) is ONE ds_read_b128.
-//   K-contiguous operand  : float4 = 4 k of one row -> 4 halves -> one ds_write_b64;
-//   row-contiguous operand: every thread loads a 4(k) x 4(row) micro-tile (4 float4, lanes
-//     spread over 8 k-quads x 8 row-quads: 128-byte global segments), transposes it in
-//     registers and writes 4 x ds_write_b64 (conflict-free with this lane order).
+// Two kernels:
+//   gemm_h16_kernel  fp32 operands in memory, rounded in registers on their way into LDS (the public
+//                    sctc_gemm_h16 entry).  K tile 32.
+//   gemm_x16_kernel  operands ALREADY 16-bit in memory: the shadow copies the engine's producers write
+//                    (GEMM epilogues, gather, adds, converts).  K tile 64: one K-contiguous row of a
+//                    tile is then a full 128-byte line.  Ablation on the MI355X (8192^3, 256x256 tile):
+//                    MFMAs + fragment reads alone 0.82 ms, + LDS stores and barrier 1.06 ms, + global
+//                    loads 2.10 ms, and MFMAs removed 2.02 ms -- the loop is bound by the number of
+//                    cache-line requests of the operand loads (not by their bytes: halving the bytes at
+//                    the same line count changed nothing), so the 16-bit kernel halves the lines per flop.
+// Tile shapes (both kernels): 128x128, 256 threads = 2x2 waves of 64x64 (2x2 MFMA tiles of
+// 32x32x16); 256x256, 512 threads = 2x4 waves of 128x64 (4x2 MFMA tiles), one block per CU, chosen
+// for large outputs.  LDS image of both operands: [row][k] halves with a row stride of k + 8
+// halves: a fragment (lane l: row l&31, 8 consecutive k at 8*(l>>5)) is ONE conflict-free ds_read_b128.
+//   K-contiguous operand  : 16-byte pieces of a row go straight to LDS (fp32: converted first);
+//   row-contiguous operand: every thread loads a 4(k) x 4(row) micro-tile, transposes it in registers
+//     (fp32: while converting; 16-bit: v_perm_b32) and writes 4 x ds_write_b64.
 #include <algorithm>
 #include <mutex>
 #include <set>
+#include <utility>
 
 #include "common.h"
 #include "gemm_f32.h"
@@ -35,16 +40,31 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-static constexpr int HBK = 32;
-static constexpr int HLD = HBK + 8;      // LDS row stride in halves (80 B)
+// compile-time loop: the accumulator tiles must be indexed by constants everywhere, or the whole
+// acc[][] array is demoted to scratch memory (with 8 tiles per wave `#pragma unroll` alone left the
+// epilogue's tile loop rolled, and every MFMA of the main loop then went through scratch)
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 template <int BIG> struct HTile;
 template <> struct HTile<0> { static constexpr int BM = 128, BN = 128, NT = 256, WGN = 2, TM = 2, TN = 2; };
 template <> struct HTile<1> { static constexpr int BM = 256, BN = 256, NT = 512, WGN = 4, TM = 4, TN = 2; };
 #ifndef SCTC_H16_OCC
 #define SCTC_H16_OCC 3
 #endif
-static constexpr int H_OCC = SCTC_H16_OCC;
+static constexpr int H_OCC = SCTC_H16_OCC;     // 128x128 tile, fp32 operands: blocks per CU
+static constexpr int X_OCC = 2;                // 128x128 tile, 16-bit operands (K tile 64: 72 KiB of LDS)
 
 template <bool BF> struct H16;
 template <> struct H16<false> {
@@ -59,6 +79,10 @@ template <> struct H16<false> {
     {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ float tofloat(unsigned h)
+    {
+        return (float)__builtin_bit_cast(_Float16, (unsigned short)h);
+    }
 };
 template <> struct H16<true> {
     using V8 = b16x8;
@@ -72,31 +96,182 @@ template <> struct H16<true> {
     {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ float tofloat(unsigned h) { return __uint_as_float(h << 16); }
 };
+
+// XCD-aware, bijective block remap (block b runs on XCD b % 8): an XCD walks consecutive tiles
+__device__ __forceinline__ int h16_swizzle(int nblk)
+{
+    const int bid = blockIdx.x, q = nblk / 8, r = nblk % 8, xcd = bid % 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+}
+
+// One k-tile of MFMAs from the LDS image (LDH = row stride in halves, KB = k per tile)
+template <bool BF, int TM, int TN, int KB, int LDH>
+__device__ __forceinline__ void h16_compute(const unsigned short* a, const unsigned short* b,
+                                            f32x16 (&acc)[TM][TN])
+{
+    using HT = H16<BF>;
+    using V8 = typename HT::V8;
+#pragma unroll
+    for (int ks = 0; ks < KB / 16; ++ks) {
+        V8 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const V8*>(a + i * 32 * LDH + 16 * ks);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const V8*>(b + j * 32 * LDH + 16 * ks);
+        // operands SWAPPED (B fragment first): the accumulator tile is then the transpose of the
+        // 32x32 output block -- lane l owns output ROW l & 31 and, per group of 4 accumulator
+        // registers, 4 CONSECUTIVE COLUMNS -- so the epilogue stores 16 B (fp32) / 8 B (16-bit
+        // shadows) per lane instead of 4 B / 2 B
+        static_for<TM * TN>([&](auto IJ) {
+            constexpr int i = decltype(IJ)::value / TN, j = decltype(IJ)::value % TN;
+            acc[i][j] = HT::mfma(bf[j], af[i], acc[i][j]);
+        });
+    }
+}
+
+// Epilogue shared by both kernels.  With the swapped MFMA operands accumulator register r of lane l
+// is D[row = l & 31][col = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)] of the 32x32 block: 4 consecutive
+// columns per register quad.  bias / relu / mask / addend / accumulate like gemm_f32.hip, plus the
+// optional 16-bit shadow copies of the result (C16a float16, C16b bfloat16); split-K partials go to the
+// workspace raw.  Vector path (16-byte fp32, 8-byte 16-bit accesses) when every pointer / stride
+// allows it, element-wise otherwise.
+template <int TM, int TN>
+__device__ __forceinline__ void h16_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0,
+                                             int wm, int wn, int lane)
+{
+    const int M = p.M, N = p.N;
+    const bool partial = p.splits > 1;
+    float* out = partial ? p.splitk_ws + (int64_t)blockIdx.y * M * N : p.C;
+    const int64_t ldo = partial ? N : p.ldc;
+    const bool has_mask = !partial && p.mask, has_add = !partial && p.addend;
+    const bool has_acc = !partial && p.accumulate;
+    const bool has_bias = !partial && p.bias;
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    const bool vec = (N % 4 == 0) && (ldo % 4 == 0) && al16(out) &&
+                     (!has_mask || (p.ldmask % 4 == 0 && al16(p.mask))) &&
+                     (!has_add || (p.ldadd % 4 == 0 && al16(p.addend))) &&
+                     (!has_acc || (p.ldc % 4 == 0 && al16(p.C))) && (!has_bias || al16(p.bias)) &&
+                     (partial || ((!p.C16a || (p.ldc16 % 4 == 0 && ((uintptr_t)p.C16a & 7) == 0)) &&
+                                  (!p.C16b || (p.ldc16 % 4 == 0 && ((uintptr_t)p.C16b & 7) == 0))));
+    static_for<TM * TN>([&](auto IJ) {
+        constexpr int i = decltype(IJ)::value / TN, j = decltype(IJ)::value % TN;
+        const int row = m0 + wm * (TM * 32) + i * 32 + (lane & 31);
+        const int cbase = n0 + wn * (TN * 32) + j * 32 + 4 * (lane >> 5);
+        const int64_t rc = min(row, M - 1);       // loads from clamped addresses; never stored
+        static_for<4>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            const int col = cbase + 8 * g;
+            float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            if (vec) {
+                const int colc = min(col, N - 4);
+                if (!partial) {
+                    if (has_bias) {
+                        const float4 b = *reinterpret_cast<const float4*>(p.bias + colc);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (has_mask) {
+                        const float4 m = *reinterpret_cast<const float4*>(p.mask + rc * p.ldmask + colc);
+                        v[0] = m.x > 0.f ? v[0] : 0.f; v[1] = m.y > 0.f ? v[1] : 0.f;
+                        v[2] = m.z > 0.f ? v[2] : 0.f; v[3] = m.w > 0.f ? v[3] : 0.f;
+                    }
+                    if (has_add) {
+                        const float4 a = *reinterpret_cast<const float4*>(p.addend + rc * p.ldadd + colc);
+                        v[0] += p.add_scale * a.x; v[1] += p.add_scale * a.y;
+                        v[2] += p.add_scale * a.z; v[3] += p.add_scale * a.w;
+                    }
+                    if (has_acc) {
+                        const float4 c = *reinterpret_cast<const float4*>(p.C + rc * p.ldc + colc);
+                        v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
+                    }
+                }
+                if (row < M && col < N) {
+                    *reinterpret_cast<float4*>(out + (int64_t)row * ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (!partial) {
+                        if (p.C16a) {
+                            const h16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                            *reinterpret_cast<h16x4*>(p.C16a + (int64_t)row * p.ldc16 + col) = h;
+                        }
+                        if (p.C16b) {
+                            const b16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                            *reinterpret_cast<b16x4*>(p.C16b + (int64_t)row * p.ldc16 + col) = h;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = col + e;
+                    if (row < M && c < N) {
+                        float x = v[e];
+                        if (!partial) {
+                            if (has_bias) x += p.bias[c];
+                            if (p.relu) x = fmaxf(x, 0.f);
+                            if (has_mask) x = p.mask[(int64_t)row * p.ldmask + c] > 0.f ? x : 0.f;
+                            if (has_add) x += p.add_scale * p.addend[(int64_t)row * p.ldadd + c];
+                            if (has_acc) x += p.C[(int64_t)row * p.ldc + c];
+                            if (p.C16a) p.C16a[(int64_t)row * p.ldc16 + c] = __builtin_bit_cast(unsigned short, (_Float16)x);
+                            if (p.C16b) p.C16b[(int64_t)row * p.ldc16 + c] = __builtin_bit_cast(unsigned short, (__bf16)x);
+                        }
+                        out[(int64_t)row * ldo + c] = x;
+                    }
+                }
+            }
+        });
+    });
+}
+
+// column sums of a row-contiguous A operand (bias gradient): asum[e] holds this thread's partial
+// for row 4*rq + e; the KQ lanes that share a row quad are adjacent (lane bits 0..log2(KQ)-1)
+template <int KQ>
+__device__ __forceinline__ void h16_colsum_out(const GemmArgs& p, float (&asum)[4], int m0, int rq, int kq)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = asum[e];
+#pragma unroll
+        for (int off = 1; off < KQ; off <<= 1) v += __shfl_xor(v, off, 64);
+        asum[e] = v;
+    }
+    if (kq == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + 4 * rq + e;
+            if (m < p.M) {
+                if (p.splits > 1)
+                    p.splitk_ws[(int64_t)p.splits * p.M * p.N + (int64_t)blockIdx.y * p.M + m] = asum[e];
+                else
+                    p.colsum_a[m] = p.accumulate ? p.colsum_a[m] + asum[e] : asum[e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ fp32 operands in memory
 
 template <bool AK, bool BKC, bool BF, int BIG>
 __global__ __launch_bounds__(HTile<BIG>::NT, BIG ? 2 : H_OCC) void gemm_h16_kernel(GemmArgs p)
 {
     constexpr int HBM = HTile<BIG>::BM, HBN = HTile<BIG>::BN, NT = HTile<BIG>::NT;
     constexpr int WGN = HTile<BIG>::WGN, TM = HTile<BIG>::TM, TN = HTile<BIG>::TN;
+    constexpr int HBK = 32, HLD = HBK + 8;
     using HT = H16<BF>;
-    using V8 = typename HT::V8;
     using V4 = typename HT::V4;
     extern __shared__ __attribute__((aligned(16))) unsigned short hsmem[];
     constexpr int OP = HBM * HLD;                 // halves per operand per buffer (HBM == HBN)
-    unsigned short* As = hsmem;                   // [2][128][HLD]
+    unsigned short* As = hsmem;                   // [2][HBM][HLD]
     unsigned short* Bs = hsmem + 2 * OP;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int M = p.M, N = p.N, K = p.K;
     const int mt = (M + HBM - 1) / HBM, nt = (N + HBN - 1) / HBN;
-    const int nblk = mt * nt;
-    int swz;   // XCD-aware, bijective remap (block b runs on XCD b % 8)
-    {
-        const int bid = blockIdx.x, q = nblk / 8, r = nblk % 8, xcd = bid % 8;
-        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-    }
+    const int swz = h16_swizzle(mt * nt);
     const int tile_n = swz % nt, tile_m = swz / nt;
     const int m0 = tile_m * HBM, n0 = tile_n * HBN;
     const int ktiles = (K + HBK - 1) / HBK;
@@ -105,22 +280,18 @@ __global__ __launch_bounds__(HTile<BIG>::NT, BIG ? 2 : H_OCC) void gemm_h16_kern
     const int kt_end = min(ktiles, kt_beg + per);
 
     f32x16 acc[TM][TN];
+    static_for<TM * TN>([&](auto IJ) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[decltype(IJ)::value / TN][decltype(IJ)::value % TN][r] = 0.f;
+    });
 
     const bool do_colsum = !AK && p.colsum_a != nullptr && tile_n == 0;
     float asum[4] = {0.f, 0.f, 0.f, 0.f};    // row-contiguous A: sums over k of this thread's 4 rows
-
+    const int kq = tid & 7;                  // K-contiguous: item q -> row (tid + NT q) / 8, k quad kq
+                                             // row-contiguous: k quad kq, row quad tid >> 3
     if (kt_beg < kt_end) {
         float4 ra[4], rb[4];
         const int Kc4 = (K - 1) & ~3, Kc1 = K - 1;
-        // K-contiguous: item q -> row (tid + 256 q) / 8, k quad (tid & 7)
-        // row-contiguous: k quad = tid & 7, row quad = tid >> 3
-        const int kq = tid & 7;
         const float* pa[4];
         const float* pb[4];
         int ia[4], ib[4];
@@ -235,101 +406,193 @@ __global__ __launch_bounds__(HTile<BIG>::NT, BIG ? 2 : H_OCC) void gemm_h16_kern
         for (int kt = kt_beg; kt < kt_end; ++kt) {
             const bool more = kt + 1 < kt_end;
             if (more) gload(kt + 1);          // in flight behind this tile's MFMAs
-            const unsigned short* a = As + buf * OP + (wm * (TM * 32) + li) * HLD + 8 * kg;
-            const unsigned short* b = Bs + buf * OP + (wn * (TN * 32) + li) * HLD + 8 * kg;
-#pragma unroll
-            for (int ks = 0; ks < HBK / 16; ++ks) {
-                V8 af[TM], bf[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const V8*>(a + i * 32 * HLD + 16 * ks);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const V8*>(b + j * 32 * HLD + 16 * ks);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = HT::mfma(af[i], bf[j], acc[i][j]);
-            }
+            h16_compute<BF, TM, TN, HBK, HLD>(As + buf * OP + (wm * (TM * 32) + li) * HLD + 8 * kg,
+                                              Bs + buf * OP + (wn * (TN * 32) + li) * HLD + 8 * kg, acc);
             if (more) lstore(buf ^ 1, kt + 1);
             __syncthreads();
             buf ^= 1;
         }
     }
-
     if constexpr (!AK) {
-        if (do_colsum) {   // block-uniform
-            // the 8 lanes that share a row quad (lane bits 0..2 = k quad) hold partial sums
+        if (do_colsum) h16_colsum_out<8>(p, asum, m0, tid >> 3, kq);   // block-uniform
+    }
+    h16_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------ 16-bit operands in memory
+
+// KC: both operands K-contiguous (forward, delta propagation with W^T) or both row-contiguous
+// (weight gradients).  K tile 64; lda / ldb count 16-bit elements.
+template <bool KC, bool BF, int BIG>
+__global__ __launch_bounds__(HTile<BIG>::NT, BIG ? 2 : X_OCC) void gemm_x16_kernel(GemmArgs p)
+{
+    constexpr int HBM = HTile<BIG>::BM, HBN = HTile<BIG>::BN, NT = HTile<BIG>::NT;
+    constexpr int WGN = HTile<BIG>::WGN, TM = HTile<BIG>::TM, TN = HTile<BIG>::TN;
+    constexpr int KB = 64, LDH = KB + 8;          // 144-byte LDS rows
+    constexpr int NLK = HBM * (KB / 8) / NT;      // K-contiguous: 16-byte pieces per thread and operand (4)
+    constexpr int KQ = KB / 4;                    // row-contiguous: k quads per tile (16)
+    constexpr int NMT = KQ * (HBM / 4) / NT;      // ... micro-tiles per thread and operand (2)
+    using HT = H16<BF>;
+    extern __shared__ __attribute__((aligned(16))) unsigned short hsmem[];
+    constexpr int OP = HBM * LDH;
+    unsigned short* As = hsmem;                   // [2][HBM][LDH]
+    unsigned short* Bs = hsmem + 2 * OP;
+    const unsigned short* A16 = reinterpret_cast<const unsigned short*>(p.A);
+    const unsigned short* B16 = reinterpret_cast<const unsigned short*>(p.B);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int M = p.M, N = p.N, K = p.K;
+    const int mt = (M + HBM - 1) / HBM, nt = (N + HBN - 1) / HBN;
+    const int swz = h16_swizzle(mt * nt);
+    const int tile_n = swz % nt, tile_m = swz / nt;
+    const int m0 = tile_m * HBM, n0 = tile_n * HBN;
+    const int ktiles = (K + KB - 1) / KB;
+    const int per = (ktiles + p.splits - 1) / p.splits;
+    const int kt_beg = blockIdx.y * per;
+    const int kt_end = min(ktiles, kt_beg + per);
+
+    f32x16 acc[TM][TN];
+    static_for<TM * TN>([&](auto IJ) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = asum[e];
-                v += __shfl_xor(v, 1, 64);
-                v += __shfl_xor(v, 2, 64);
-                v += __shfl_xor(v, 4, 64);
-                asum[e] = v;
+        for (int r = 0; r < 16; ++r) acc[decltype(IJ)::value / TN][decltype(IJ)::value % TN][r] = 0.f;
+    });
+    const bool do_colsum = !KC && p.colsum_a != nullptr && tile_n == 0;
+    float asum[NMT][4];
+#pragma unroll
+    for (int u = 0; u < NMT; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asum[u][e] = 0.f;
+
+    if (kt_beg < kt_end) {
+        u32x4 ha[NLK], hb[NLK];                   // K-contiguous staging
+        u32x2 ga[NMT][4], gb[NMT][4];             // row-contiguous staging: 4 k-rows x 4 rows
+        const unsigned short* pa16[KC ? NLK : NMT];
+        const unsigned short* pb16[KC ? NLK : NMT];
+        int ia[NMT][4], ib[NMT][4];
+        const int Kc8 = (K - 1) & ~7, Kc1 = K - 1;
+        if constexpr (KC) {
+#pragma unroll
+            for (int q = 0; q < NLK; ++q) {
+                const int f = tid + NT * q, row = f / (KB / 8), k8 = 8 * (f % (KB / 8));
+                pa16[q] = A16 + (int64_t)min(m0 + row, M - 1) * p.lda + k8;
+                pb16[q] = B16 + (int64_t)min(n0 + row, N - 1) * p.ldb + k8;
             }
-            if ((tid & 7) == 0) {
+        } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int m = m0 + 4 * (tid >> 3) + e;
-                    if (m < M) {
-                        if (p.splits > 1)
-                            p.splitk_ws[(int64_t)p.splits * M * N + (int64_t)blockIdx.y * M + m] = asum[e];
-                        else
-                            p.colsum_a[m] = p.accumulate ? p.colsum_a[m] + asum[e] : asum[e];
+            for (int u = 0; u < NMT; ++u) {
+                const int mtile = tid + NT * u, kq = mtile % KQ, rq = mtile / KQ;
+                pa16[u] = A16 + min(m0 + 4 * rq, (M - 1) & ~3);
+                pb16[u] = B16 + min(n0 + 4 * rq, (N - 1) & ~3);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = min(kt_beg * KB + 4 * kq + j, Kc1);
+                    ia[u][j] = p.idx_a ? p.idx_a[k] : k;
+                    ib[u][j] = p.idx_b ? p.idx_b[k] : k;
+                }
+            }
+        }
+        auto gload = [&](int kt) {
+            const int k0 = kt * KB;
+            if constexpr (KC) {
+#pragma unroll
+                for (int q = 0; q < NLK; ++q) {
+                    const int k8 = 8 * ((tid + NT * q) % (KB / 8));
+                    const int off = min(k0, Kc8 - k8);         // the pointers already include k8
+                    ha[q] = *reinterpret_cast<const u32x4*>(pa16[q] + off);
+                    hb[q] = *reinterpret_cast<const u32x4*>(pb16[q] + off);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NMT; ++u) {
+                    const int kq = (tid + NT * u) % KQ;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ga[u][j] = *reinterpret_cast<const u32x2*>(pa16[u] + (uint32_t)ia[u][j] * (uint32_t)p.lda);
+                        gb[u][j] = *reinterpret_cast<const u32x2*>(pb16[u] + (uint32_t)ib[u][j] * (uint32_t)p.ldb);
+                        const int kn = min(k0 + KB + 4 * kq + j, Kc1);
+                        ia[u][j] = p.idx_a ? p.idx_a[kn] : kn;       // rows of the NEXT tile, one tile ahead
+                        ib[u][j] = p.idx_b ? p.idx_b[kn] : kn;
                     }
                 }
+            }
+        };
+        auto lstore = [&](int buf, int kt) {
+            unsigned short* a = As + buf * OP;
+            unsigned short* b = Bs + buf * OP;
+            const bool tail = (kt + 1) * KB > K;     // uniform
+            if constexpr (KC) {
+#pragma unroll
+                for (int q = 0; q < NLK; ++q) {
+                    const int f = tid + NT * q, r = f / (KB / 8), k8 = 8 * (f % (KB / 8));
+                    const bool z = tail && kt * KB + k8 >= K;        // K % 8 == 0 here
+                    const u32x4 zero = {0u, 0u, 0u, 0u};
+                    *reinterpret_cast<u32x4*>(a + r * LDH + k8) = z ? zero : ha[q];
+                    *reinterpret_cast<u32x4*>(b + r * LDH + k8) = z ? zero : hb[q];
+                }
+            } else {
+                // 4 x 4 transpose of 16-bit values: row r + e gets {k0, k1, k2, k3}
+                auto tr = [](const u32x2 (&g)[4], unsigned short* dst) {
+                    const u32x2 o0 = {__builtin_amdgcn_perm(g[1][0], g[0][0], 0x05040100u), __builtin_amdgcn_perm(g[3][0], g[2][0], 0x05040100u)};
+                    const u32x2 o1 = {__builtin_amdgcn_perm(g[1][0], g[0][0], 0x07060302u), __builtin_amdgcn_perm(g[3][0], g[2][0], 0x07060302u)};
+                    const u32x2 o2 = {__builtin_amdgcn_perm(g[1][1], g[0][1], 0x05040100u), __builtin_amdgcn_perm(g[3][1], g[2][1], 0x05040100u)};
+                    const u32x2 o3 = {__builtin_amdgcn_perm(g[1][1], g[0][1], 0x07060302u), __builtin_amdgcn_perm(g[3][1], g[2][1], 0x07060302u)};
+                    *reinterpret_cast<u32x2*>(dst + 0 * LDH) = o0;
+                    *reinterpret_cast<u32x2*>(dst + 1 * LDH) = o1;
+                    *reinterpret_cast<u32x2*>(dst + 2 * LDH) = o2;
+                    *reinterpret_cast<u32x2*>(dst + 3 * LDH) = o3;
+                };
+#pragma unroll
+                for (int u = 0; u < NMT; ++u) {
+                    const int mtile = tid + NT * u, kq = mtile % KQ, rq = mtile / KQ;
+                    if (tail) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (kt * KB + 4 * kq + j >= K) { ga[u][j] = {0u, 0u}; gb[u][j] = {0u, 0u}; }
+                    }
+                    tr(ga[u], a + 4 * rq * LDH + 4 * kq);
+                    tr(gb[u], b + 4 * rq * LDH + 4 * kq);
+                    if (do_colsum) {     // bias gradient from the (rounded) 16-bit deltas, fp32 sums
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            asum[u][0] += HT::tofloat(ga[u][j][0] & 0xffffu);
+                            asum[u][1] += HT::tofloat(ga[u][j][0] >> 16);
+                            asum[u][2] += HT::tofloat(ga[u][j][1] & 0xffffu);
+                            asum[u][3] += HT::tofloat(ga[u][j][1] >> 16);
+                        }
+                    }
+                }
+            }
+        };
+
+        gload(kt_beg);
+        lstore(0, kt_beg);
+        __syncthreads();
+        int buf = 0;
+        const int li = lane & 31, kg = lane >> 5;
+        for (int kt = kt_beg; kt < kt_end; ++kt) {
+            const bool more = kt + 1 < kt_end;
+            if (more) gload(kt + 1);          // in flight behind this tile's MFMAs
+            h16_compute<BF, TM, TN, KB, LDH>(As + buf * OP + (wm * (TM * 32) + li) * LDH + 8 * kg,
+                                             Bs + buf * OP + (wn * (TN * 32) + li) * LDH + 8 * kg, acc);
+            if (more) lstore(buf ^ 1, kt + 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    if constexpr (!KC) {
+        if (do_colsum) {   // block-uniform
+#pragma unroll
+            for (int u = 0; u < NMT; ++u) {
+                const int mtile = tid + NT * u;
+                h16_colsum_out<KQ>(p, asum[u], m0, mtile / KQ, mtile % KQ);
             }
         }
     }
-
-    // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool partial = p.splits > 1;
-    float* out = partial ? p.splitk_ws + (int64_t)blockIdx.y * M * N : p.C;
-    const int64_t ldo = partial ? N : p.ldc;
-    const bool has_mask = !partial && p.mask, has_add = !partial && p.addend;
-    const bool has_acc = !partial && p.accumulate;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
-            const int rbase = m0 + wm * (TM * 32) + i * 32 + 4 * (lane >> 5);
-            const bool col_ok = col < N;
-            const int colc = min(col, N - 1);
-            const float bias = (!partial && p.bias) ? p.bias[colc] : 0.f;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {     // 8 rows at a time: aux operands fetched as a batch
-                float mk[8], ad[8], cc[8];
-#pragma unroll
-                for (int r8 = 0; r8 < 8; ++r8) {
-                    const int r = half * 8 + r8;
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    // unconditional loads from clamped addresses (a load behind a per-lane
-                    // condition becomes an exec-mask branch with spills around it); out-of-range
-                    // elements are never stored
-                    const int64_t rc = min(row, M - 1);
-                    mk[r8] = has_mask ? p.mask[rc * p.ldmask + colc] : 1.f;
-                    ad[r8] = has_add ? p.addend[rc * p.ldadd + colc] : 0.f;
-                    cc[r8] = has_acc ? p.C[rc * p.ldc + colc] : 0.f;
-                }
-#pragma unroll
-                for (int r8 = 0; r8 < 8; ++r8) {
-                    const int r = half * 8 + r8;
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (col_ok && row < M) {
-                        float v = acc[i][j][r];
-                        if (!partial) {
-                            v += bias;
-                            if (p.relu) v = fmaxf(v, 0.f);
-                            if (has_mask) v = mk[r8] > 0.f ? v : 0.f;
-                            if (has_add) v += p.add_scale * ad[r8];
-                            if (has_acc) v += cc[r8];
-                        }
-                        out[(int64_t)row * ldo + col] = v;
-                    }
-                }
-            }
-        }
+    h16_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
+
+// ------------------------------------------------------------------ host side
 
 // the 256x256 tile when the output is large enough to give every CU whole tiles of it and its
 // padding does not cost more than it saves (H = 1824 = 7.1 x 256 pads 12 %)
@@ -346,15 +609,15 @@ static int h16_pick_big(int M, int N)
 int64_t gemm_h16_plan_splits(int M, int N, int K, int* splits)
 {
     const int big = h16_pick_big(M, N);
-    const int bm = big ? 256 : 128, occ = big ? 1 : H_OCC;
+    const int bm = big ? 256 : 128, occ = big ? 1 : 2;
     const int mt = (M + bm - 1) / bm, nt = (N + bm - 1) / bm;
-    const int ktiles = (K + HBK - 1) / HBK;
+    const int ktiles = (K + 63) / 64;
     int s = 1;
-    // fill whole rounds of 256 CUs x `occ` resident blocks, >= 8 K tiles (256 k) per split
+    // fill whole rounds of 256 CUs x `occ` resident blocks, >= 4 K tiles of 64 (256 k) per split
     const int tiles = mt * nt, slots = 256 * occ;
     if (tiles < 2 * slots) {
         double best = 0.0;
-        const int smax = std::min(64, std::max(1, ktiles / 8));
+        const int smax = std::min(64, std::max(1, ktiles / 4));
         for (int c = 1; c <= smax; ++c) {
             const int blocks = tiles * c;
             const int rounds = (blocks + slots - 1) / slots;
@@ -366,32 +629,44 @@ int64_t gemm_h16_plan_splits(int M, int N, int K, int* splits)
     return s > 1 ? (int64_t)s * M * (N + 1) : 0;
 }
 
+static int set_lds_once(void (*kern)(GemmArgs), size_t smem)
+{
+    if (smem <= 64 * 1024) return SCTC_OK;
+    static std::mutex mu;
+    static std::set<const void*> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done.count(reinterpret_cast<const void*>(kern))) {
+        SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        done.insert(reinterpret_cast<const void*>(kern));
+    }
+    return SCTC_OK;
+}
+
 template <int BIG>
 static int launch_h16(const GemmArgs& a, hipStream_t stream)
 {
     constexpr int BM = HTile<BIG>::BM, BN = HTile<BIG>::BN, NT = HTile<BIG>::NT;
     const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
     dim3 grid(mt * nt, a.splits), block(NT);
-    const size_t smem = sizeof(unsigned short) * 2 * (BM + BN) * HLD;     // 2 buffers x (A + B) tiles
     void (*kern)(GemmArgs) = nullptr;
     const bool bf = a.prec == 2;
+    size_t smem;
+    if (a.in16) {     // both operands 16-bit in memory, same layout (checked by launch_gemm_f32)
+        smem = sizeof(unsigned short) * 2 * (BM + BN) * (64 + 8);
+        if (a.a_kcontig) kern = bf ? gemm_x16_kernel<true, true, BIG> : gemm_x16_kernel<true, false, BIG>;
+        else kern = bf ? gemm_x16_kernel<false, true, BIG> : gemm_x16_kernel<false, false, BIG>;
+    } else {
+        smem = sizeof(unsigned short) * 2 * (BM + BN) * (32 + 8);
 #define SCTC_H16_PICK(AKV, BKV)                                                              \
     kern = bf ? gemm_h16_kernel<AKV, BKV, true, BIG> : gemm_h16_kernel<AKV, BKV, false, BIG>
-    if (a.a_kcontig && a.b_kcontig) SCTC_H16_PICK(true, true);
-    else if (a.a_kcontig && !a.b_kcontig) SCTC_H16_PICK(true, false);
-    else if (!a.a_kcontig && a.b_kcontig) SCTC_H16_PICK(false, true);
-    else SCTC_H16_PICK(false, false);
+        if (a.a_kcontig && a.b_kcontig) SCTC_H16_PICK(true, true);
+        else if (a.a_kcontig && !a.b_kcontig) SCTC_H16_PICK(true, false);
+        else if (!a.a_kcontig && a.b_kcontig) SCTC_H16_PICK(false, true);
+        else SCTC_H16_PICK(false, false);
 #undef SCTC_H16_PICK
-    if (smem > 64 * 1024) {
-        static std::mutex mu;
-        static std::set<const void*> done;
-        std::lock_guard<std::mutex> lock(mu);
-        if (!done.count(reinterpret_cast<const void*>(kern))) {
-            SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            done.insert(reinterpret_cast<const void*>(kern));
-        }
     }
+    SCTC_TRY(set_lds_once(kern, smem));
     hipLaunchKernelGGL(kern, grid, block, smem, stream, a);
     SCTC_HIP_TRY(hipGetLastError());
     return SCTC_OK;

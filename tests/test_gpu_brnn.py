@@ -520,7 +520,8 @@ def test_async_entry_matches_sync(mods):
     want = 0.01 * net._params.cpu().numpy()
     for lo, hi in net.noreg_ranges().reshape(-1, 2):
         want[lo:hi] = 0.0                                           # biases carry no L2 term
-    np.testing.assert_allclose(diff, want, rtol=1e-4, atol=1e-6)
+    # difference of two fp32 gradients of magnitude ~10: a few ulps of THEM, not of reg * W
+    np.testing.assert_allclose(diff, want, rtol=1e-4, atol=2e-5)
     buckets = net.gradBuckets()
     assert all(ev for ev, _, _ in buckets)
     spans = sorted((s, e) for _, s, e in buckets)
@@ -528,4 +529,4 @@ def test_async_entry_matches_sync(mods):
     assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))     # exact cover, no overlap
     assert buckets[0][1] == int(net._infos[2 * NL].offset)          # output layer first (brnnet.py:191-193)
     assert [s for _, s, _ in buckets].index(int(net._infos[2 * (NL + 1)].offset)) == NL - TL + 1   # Wf right after the temporal layer
-    assert net.regCostDev().item() == pytest.approx(net.regcost, rel=1e-9)
+    assert net.regCostDev().item() == pytest.approx(net.regcost, rel=1e-6)   # engine: fp32 partial sums
