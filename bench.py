@@ -161,7 +161,10 @@ def main():
     torch.cuda.set_device(local % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":                      # bind the communicator to this rank's GPU up front
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     import _sctc
@@ -352,6 +355,7 @@ def main():
                     for k in ("softmax_rows_kernel", "ctc_lattice_kernel", "ctc_grad_kernel"))
         if world == 1 and not args.no_side:
             side_measurements(out, net, feats, labels, Ts, rs, torch, B, T, D)
+            f32_split_bf16x3(out, torch, cfg, labels, feats, net)
             ctc_saturation(out, torch, A, T, U)
             del net, feats, dev_bufs
             torch.cuda.empty_cache()
@@ -459,6 +463,59 @@ def ctc_saturation(out, torch, A, T, U):
                 "lattice recursion is latency/compute-bound, not HBM-bound (DESIGN.md 4.3)" % (T, U)}
 
 
+def f32_split_bf16x3(out, torch, cfg, labels, feats, net32):
+    """The headline workload with the time-batched contractions on the bfloat16 matrix cores: every
+    fp32 operand split exactly into three bfloat16 terms, six cross products, fp32 accumulation
+    (NNet(..., gemm="bf16x3"), gemm_s3.hip).  fp32-accurate -- the error against a float64 product
+    equals the fp32 fma chain's (tests/test_gpu_bf16x3.py) -- but NOT the reference's instruction, so
+    it is opt-in and a side field, never `value`."""
+    from nnets import brnnet
+    import _sctc
+    D, A, H, NL, TL, T, U, B = (cfg[k] for k in ("D", "A", "H", "NL", "TL", "T", "U", "B"))
+    np.random.seed(0)
+    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B, gemm="bf16x3")
+    net.initParams()                        # same seed -> the same weights as the fp32 net
+    Ts = [T] * B
+    c32, _, _ = net32.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+    g32 = net32.grad.flat.clone()
+    c3, _, _ = net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+    g3 = net.grad.flat
+    gdiff = float((g3 - g32).double().norm() / g32.double().norm())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    L = _sctc.lib()
+    L.sctc_brnn_set_profiling(net._h, 1)
+    net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+    arr = (ctypes.c_float * len(PHASES))()
+    L.sctc_brnn_phase_ms(net._h, arr)
+    L.sctc_brnn_set_profiling(net._h, 0)
+    ph = dict(zip(PHASES, [float(v) for v in arr]))
+    tot, gm, rc = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    mb, keep = net._minibatch(feats, Ts, labels)
+    L.sctc_brnn_flops(net._h, ctypes.byref(mb), ctypes.byref(tot), ctypes.byref(gm), ctypes.byref(rc))
+    gemm_ms = ph["fwd_gemm"] + ph["bwd_gemm"]
+    ach = gm.value / (gemm_ms * 1e-3) / 1e12
+    out["f32_split_bf16x3"] = {
+        "workload": "the headline workload (cfg-3, minibatch %d, HBM-resident features), gemm='bf16x3'" % B,
+        "dtype": "f32 operands and results; products as 6 bf16 x bf16 terms of an exact 3-term split, f32 accumulate",
+        "value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "phase_ms": ph,
+        "max_cost_rel_diff_vs_f32_path": float(np.max(np.abs(c3 - c32) / np.abs(c32))),
+        "grad_rel_norm_diff_vs_f32_path": gdiff,
+        "roofline_gemm": {"bound": "mfma + lds", "kernel": "gemm_s3_kernel",
+                          "achieved": ach, "unit": "TFLOP/s (algorithmic fp32 flops)",
+                          "peak": PEAK_F16_MFMA_TFLOPS / 6.0, "frac": ach / (PEAK_F16_MFMA_TFLOPS / 6.0),
+                          "note": "peak = dense bf16 MFMA peak / 6 executed products per algorithmic product; "
+                                  "a register-only loop of v_mfma_f32_32x32x16_bf16 on random operands sustains "
+                                  "1775 TFLOP/s (tools/valu_rate.hip), i.e. 296 fp32-equivalent; ds_read_b128 "
+                                  "delivers 64 B/clk per CU, which the 64x64 wave tile needs in full"}}
+    del net
+
+
 def cfg5_fp16(out, torch):
     """BASELINE configs[4] as specified: T=8000 A=33 7x2048 (temporalLayer 4, inputDim 615) U=800,
     fp16 operands / fp32 accumulate / float64 CTC, minibatch 8 and 1 -- a side field, never `value`"""
@@ -496,11 +553,12 @@ def cfg5_fp16(out, torch):
         gemm_ms = ph["fwd_gemm"] + ph["bwd_gemm"]
         res["minibatch_%d" % B] = {
             "value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "phase_ms": ph,
-            "roofline_gemm": {"bound": "mfma", "kernel": "gemm_h16_kernel (f16 fwd / bf16 bwd operands, f32 accumulate)",
+            "roofline_gemm": {"bound": "mfma", "kernel": "gemm_x16_kernel (f16 fwd / bf16 bwd shadow operands, f32 accumulate)",
                               "achieved": gm.value / (gemm_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": gm.value / (gemm_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
-                              "note": "operands stay fp32 in HBM and are rounded on their way into LDS: "
-                                      "the kernel is bound by operand traffic (L2), not by the matrix pipes"},
+                              "note": "16-bit shadow copies of activations / deltas / weights are written by "
+                                      "their producers; the kernel is bound by the CU's load-request rate and "
+                                      "ds_read_b128 bandwidth (64 B/clk), not by the matrix pipes"},
             "us_per_recurrent_step": (ph["fwd_rec"] + ph["bwd_rec"]) * 1e3 / (2 * (T - 1)),
             "ctc_ms": ph["ctc"]}
         del net

@@ -42,6 +42,8 @@ extern "C" {
 #define SCTC_F64 1
 #define SCTC_F16 2   /* operand type of the mixed-precision GEMMs / recurrent step (fp32 accumulate) */
 #define SCTC_BF16 3
+#define SCTC_BF16X3 4 /* fp32 operands split exactly into three bfloat16 terms (x = x1 + x2 + x3), six cross
+                         products on the bfloat16 matrix cores, fp32 accumulate: an fp32-accurate GEMM */
 
 /* ---- library ---------------------------------------------------------- */
 
@@ -132,7 +134,13 @@ typedef struct sctc_brnn_config {
                                 the forward pass, bfloat16 in the backward pass: deltas need
                                 fp32's exponent range), products exact, accumulation fp32;
                                 parameters, gradients, activations in memory, softmax and the
-                                CTC lattices (float64) are unchanged */
+                                CTC lattices (float64) are unchanged.
+                                SCTC_BF16X3: fp32 semantics everywhere (same tolerances as SCTC_F32);
+                                only the time-batched contractions change instruction: each fp32
+                                operand is split exactly into three bfloat16 terms and six cross
+                                products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+                                (dropped terms <= 2^-23 of a product); recurrent step, softmax, CTC
+                                and the update stay on the fp32 / fp64 paths */
 } sctc_brnn_config;
 
 /* One parameter tensor of `stack` (brnnet.py:58-59,71-72): order
@@ -241,7 +249,8 @@ int sctc_gemm_f32(const float* A_dev, int64_t lda, int32_t a_kcontig, const floa
 /* The same contraction with both operands ROUNDED to a 16-bit type (operand_dtype = SCTC_F16 or
  * SCTC_BF16, round-to-nearest-even) on their way to the matrix cores and fp32 accumulation
  * (v_mfma_f32_32x32x16_f16 / _bf16): the GEMM of the "fp16 activations" configuration
- * (BASELINE configs[4]).  Operands and result stay fp32 in memory. */
+ * (BASELINE configs[4]).  Operands and result stay fp32 in memory.
+ * operand_dtype = SCTC_BF16X3: no rounding -- the three-term split described at sctc_brnn_config. */
 int sctc_gemm_h16(const float* A_dev, int64_t lda, int32_t a_kcontig, const float* B_dev,
                   int64_t ldb, int32_t b_kcontig, float* C_dev, int64_t ldc, int32_t M, int32_t N,
                   int32_t K, const float* bias_dev, int32_t relu, int32_t operand_dtype,

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCTC_LIB_PATH") or os.path.join(_HERE, "libsctc_hip.so")   # override: kernel-variant experiments
 
-F32, F64, F16, BF16 = 0, 1, 2, 3
+F32, F64, F16, BF16, BF16X3 = 0, 1, 2, 3, 4
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)

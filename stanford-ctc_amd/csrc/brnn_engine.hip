@@ -35,6 +35,17 @@ static constexpr int PAD = 32;
 static inline int LD(int padded_dim) { return (int)((padded_dim + 63) / 64 * 64); }
 static constexpr int CTC_LP_MAX = 2048;  // worst-case lattice row (2U+1 <= 2048)
 
+// GemmArgs::prec of the time-batched contractions for a configured operand_dtype (SCTC_BF16X3: fp32
+// operands in memory, split into three bfloat16 terms inside the GEMM -- no shadow copies)
+static int fwd_prec(int operand_dtype)
+{
+    return operand_dtype == SCTC_F16 ? 1 : (operand_dtype == SCTC_BF16X3 ? 3 : 0);
+}
+static int bwd_prec(int operand_dtype)
+{
+    return operand_dtype == SCTC_F16 ? 2 : (operand_dtype == SCTC_BF16X3 ? 3 : 0);
+}
+
 struct sctc_brnn {
     sctc_brnn_config cfg;
     int D, Dp, H, Hp, A, Ap, NL, TL;
@@ -119,8 +130,8 @@ static int derive_dims(const sctc_brnn_config* c, Dims* d)
                    c->input_dim, c->output_dim, c->layer_size, c->num_layers);
     SCTC_CHECK_ARG(c->max_frames >= 1 && c->max_utts >= 1, "brnn: bad capacity");
     SCTC_CHECK_ARG(c->output_dim <= 256, "brnn: alphabet %d > 256", c->output_dim);
-    SCTC_CHECK_ARG(c->operand_dtype == SCTC_F32 || c->operand_dtype == SCTC_F16,
-                   "brnn: operand_dtype must be SCTC_F32 or SCTC_F16 (got %d)", c->operand_dtype);
+    SCTC_CHECK_ARG(c->operand_dtype == SCTC_F32 || c->operand_dtype == SCTC_F16 || c->operand_dtype == SCTC_BF16X3,
+                   "brnn: operand_dtype must be SCTC_F32, SCTC_F16 or SCTC_BF16X3 (got %d)", c->operand_dtype);
     d->D = c->input_dim;
     d->H = c->layer_size;
     d->A = c->output_dim;
@@ -244,11 +255,11 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
         for (int l = 0; l <= d.NL; ++l) {
             const int inp = l == 0 ? d.Dp : d.Hp, outp = l == d.NL ? d.Ap : d.Hp;
             int sp = 1;
-            sk = std::max<int64_t>(sk, gemm_plan_splits(outp, inp, (int)F, &sp, c->operand_dtype ? 2 : 0));
+            sk = std::max<int64_t>(sk, gemm_plan_splits(outp, inp, (int)F, &sp, bwd_prec(c->operand_dtype)));
         }
         if (d.TL > 0) {
             int sp = 1;
-            sk = std::max<int64_t>(sk, gemm_plan_splits(d.Hp, d.Hp, (int)F, &sp, c->operand_dtype ? 2 : 0));
+            sk = std::max<int64_t>(sk, gemm_plan_splits(d.Hp, d.Hp, (int)F, &sp, bwd_prec(c->operand_dtype)));
         }
     }
     // small minibatches (few row tiles) split K in the forward / delta-propagation GEMMs as well:
@@ -457,7 +468,7 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
         g.C = dst;
         g.ldc = LD(outp);
         g.relu = (i <= h->NL && i != h->TL) ? 1 : 0;             // brnnet.py:155-157
-        g.prec = h16 ? 1 : 0;                                    // forward: float16 operands
+        g.prec = fwd_prec(h->cfg.operand_dtype);                 // SCTC_F16 -> forward: float16 operands
         if (h16) {
             g.in16 = 1;
             g.A = reinterpret_cast<const float*>(h->act16f[i - 1]);
@@ -590,8 +601,8 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
     const int64_t N = h->N;
     const int acc = (flags & SCTC_FLAG_ACCUMULATE) ? 1 : 0;
     const float reg = (flags & SCTC_FLAG_NO_REG_GRAD) ? 0.f : h->cfg.reg;
-    const int bprec = h->cfg.operand_dtype == SCTC_F16 ? 2 : 0;   // backward: bfloat16 operands
-    const bool h16 = bprec != 0;
+    const int bprec = bwd_prec(h->cfg.operand_dtype);             // SCTC_F16 -> backward: bfloat16 operands
+    const bool h16 = h->cfg.operand_dtype == SCTC_F16;            // 16-bit shadow operands
     const float* d_in = h->dlogits;
     const uint16_t* d_in16 = h->dlogits16;
     int d_in_ld = LD(h->Ap);

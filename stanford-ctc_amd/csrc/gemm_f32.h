@@ -41,7 +41,9 @@ struct GemmArgs {
     int32_t splits;
     // operand precision: 0 = fp32 (v_mfma_f32_32x32x2_f32, exact fp32 fma chain);
     // 1 = float16, 2 = bfloat16: both operands rounded to 16 bit on the way into LDS, fp32
-    // accumulate (gemm_h16.hip; the "fp16 activations" configuration)
+    // accumulate (gemm_h16.hip; the "fp16 activations" configuration);
+    // 3 = fp32 operands split exactly into three bfloat16 terms, six cross products on the
+    // bfloat16 matrix cores, fp32 accumulate: fp32-accurate (gemm_h16.hip, SCTC_BF16X3)
     int32_t prec;
     // prec != 0 only.  in16: both operands are ALREADY 16-bit in memory (float16 for prec 1,
     // bfloat16 for prec 2; `A` / `B` then point at 2-byte elements, lda / ldb count them): the
@@ -59,7 +61,10 @@ struct GemmArgs {
 int64_t gemm_plan_splits(int M, int N, int K, int* splits, int prec = 0);
 int launch_gemm_f32(GemmArgs a, hipStream_t stream);     // dispatches on a.prec
 // gemm_h16.hip
-int64_t gemm_h16_plan_splits(int M, int N, int K, int* splits);
+int64_t gemm_h16_plan_splits(int M, int N, int K, int* splits, int prec);
 int launch_gemm_h16_tiles(const GemmArgs& a, hipStream_t stream);
+// prec 3 (gemm_s3.hip)
+int64_t gemm_s3_plan_splits(int M, int N, int K, int* splits);
+int launch_gemm_s3(const GemmArgs& a, hipStream_t stream);
 
 }  // namespace sctc

@@ -421,7 +421,7 @@ int gemm_pick_shape(int M, int N)
 
 int64_t gemm_plan_splits(int M, int N, int K, int* splits, int prec)
 {
-    if (prec) return gemm_h16_plan_splits(M, N, K, splits);
+    if (prec) return gemm_h16_plan_splits(M, N, K, splits, prec);
     const ShapeInfo& sh = kShapes[gemm_pick_shape(M, N)];
     const int mt = (M + sh.bm - 1) / sh.bm, nt = (N + sh.bn - 1) / sh.bn;
     const int ktiles = (K + BK - 1) / BK;
@@ -491,7 +491,9 @@ int launch_gemm_f32(GemmArgs a, hipStream_t stream)
     if (a.splits < 1) a.splits = 1;
     if (a.splits > 1) SCTC_CHECK_ARG(a.splitk_ws != nullptr, "gemm: split-K without workspace");
     if (a.prec) {
-        SCTC_CHECK_ARG(a.prec == 1 || a.prec == 2, "gemm: unknown operand precision %d", a.prec);
+        SCTC_CHECK_ARG(a.prec >= 1 && a.prec <= 3, "gemm: unknown operand precision %d", a.prec);
+        SCTC_CHECK_ARG(a.prec != 3 || (!a.in16 && !a.C16a && !a.C16b),
+                       "gemm: the three-term split takes fp32 operands and writes no 16-bit shadows");
         SCTC_TRY(launch_gemm_h16_tiles(a, stream));
     } else {
         switch (gemm_pick_shape(a.M, a.N)) {
@@ -525,10 +527,11 @@ extern "C" int sctc_gemm_h16(const float* A_dev, int64_t lda, int32_t a_kcontig,
                              void* stream)
 {
     using namespace sctc;
-    SCTC_CHECK_ARG(operand_dtype == SCTC_F16 || operand_dtype == SCTC_BF16,
-                   "gemm_h16: operand_dtype must be SCTC_F16 or SCTC_BF16");
+    SCTC_CHECK_ARG(operand_dtype == SCTC_F16 || operand_dtype == SCTC_BF16 || operand_dtype == SCTC_BF16X3,
+                   "gemm_h16: operand_dtype must be SCTC_F16, SCTC_BF16 or SCTC_BF16X3");
     return gemm_entry(A_dev, lda, a_kcontig, B_dev, ldb, b_kcontig, C_dev, ldc, M, N, K, bias_dev,
-                      relu, workspace_dev, workspace_bytes, stream, operand_dtype == SCTC_F16 ? 1 : 2);
+                      relu, workspace_dev, workspace_bytes, stream,
+                      operand_dtype == SCTC_F16 ? 1 : (operand_dtype == SCTC_BF16 ? 2 : 3));
 }
 
 extern "C" int sctc_gemm_f32(const float* A_dev, int64_t lda, int32_t a_kcontig,

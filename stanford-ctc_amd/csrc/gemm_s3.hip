@@ -1,0 +1,299 @@
+// fp32-accurate GEMM on the bfloat16 matrix cores (GemmArgs::prec == 3, SCTC_BF16X3): the same
+// contractions as gemm_f32.hip (brnnet.py:140 fwd, :196 wgrad, :204 dgrad, :227-230 recurrent wgrad).
+//
+// Every fp32 operand element is split EXACTLY into three bfloat16 terms, x = x1 + x2 + x3
+// (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 3 x 8 significand bits, the subtractions
+// are exact), and six of the nine cross products run on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation: x1y1, x1y2, x2y1, x2y2, x1y3, x3y1.  The dropped x2y3 + x3y2 + x3y3 are below
+// 2^-23 |xy|, the same size as ONE fp32 rounding of the product; measured against a float64 product
+// the error equals that of the fp32 fma chain of gemm_f32.hip (tests/test_gpu_bf16x3.py,
+// tests/gpu_diag.py gemmx3).  Six bfloat16 MFMAs cost 6/16 of the fp32 MFMA time for the same tile.
+// Caveat: an Inf / NaN operand element turns its whole product row into NaN (Inf - Inf in the split).
+//
+// Kernel: 128x128 tile, 256 threads = 2x2 waves of 64x64, K tile 16, two blocks per CU (LDS: two
+// buffers x 6 planes x 128 rows x 48 B = 72 KiB per block).  A wave issues in order, so one K tile is a
+// software pipeline inside the instruction stream, written as 24 slots of [one MFMA + a piece of the
+// other work] fenced with sched_barrier: while the 24 MFMAs of tile t run (24 x 32 matrix-core
+// cycles) the same wave splits tile t+1 -- fetched FOUR tiles earlier into one of four rotating
+// register sets; with one set (one tile of slack) the step time WAS the memory latency -- into the
+// other LDS buffer and requests tile t+5.  The second block of the CU fills the fragment-read and
+// barrier gaps.  History (64000 x 2048 x 2048, fp32 kernel 4.4 ms): un-pipelined, 2 blocks per CU, one
+// LDS buffer 3.45 ms = 2.11 ms without the MFMAs + 1.29 ms of ideal MFMA time, i.e. fully serialised;
+// K tile 32 pipelined with one register set, one block per CU 2.93 ms.
+#include <algorithm>
+#include <mutex>
+#include <set>
+
+#include "common.h"
+#include "gemm_f32.h"
+#include "gemm_h16_dev.h"
+
+namespace sctc {
+
+static constexpr int S3_BM = 128, S3_BN = 128, S3_NT = 256, S3_BK = 16, S3_LD = S3_BK + 8;   // 48-byte LDS rows
+static constexpr int S3_D = 4;                       // prefetch distance in K tiles (register sets)
+static constexpr int S3_OP = S3_BM * S3_LD;          // halves per operand plane (S3_BM == S3_BN)
+static constexpr int S3_BUF = 6 * S3_OP;             // halves per buffer: A planes 0..2, B planes 0..2
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+
+// exact three-term split of two floats; term t of both packed into one dword (element 0 low).
+// 9 VALU per pair: v_cvt_pk_bf16_f32, shift + and back to fp32, v_pk_add_f32 -- twice, + the last convert
+__device__ __forceinline__ void split3_pair(float a, float b, uint32_t (&t)[3])
+{
+    f32x2 x = {a, b};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const b16x2 h = __builtin_convertvector(x, b16x2);
+        t[k] = __builtin_bit_cast(uint32_t, h);
+        if (k < 2) {
+            const f32x2 f = {__uint_as_float(t[k] << 16), __uint_as_float(t[k] & 0xffff0000u)};
+            x = x - f;
+        }
+    }
+}
+
+// four consecutive k of one row -> the three planes (one ds_write_b64 each)
+__device__ __forceinline__ void put4(unsigned short* dst, float x0, float x1, float x2, float x3)
+{
+    uint32_t lo[3], hi[3];
+    split3_pair(x0, x1, lo);
+    split3_pair(x2, x3, hi);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2*>(dst + t * S3_OP) = u32x2{lo[t], hi[t]};
+}
+
+template <bool AK, bool BKC>
+__global__ __launch_bounds__(S3_NT, 2) void gemm_s3_kernel(GemmArgs p)
+{
+    constexpr int TM = 2, TN = 2;
+    using HT = H16<true>;
+    extern __shared__ __attribute__((aligned(16))) unsigned short hsmem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int M = p.M, N = p.N, K = p.K;
+    const int mt = (M + S3_BM - 1) / S3_BM, nt = (N + S3_BN - 1) / S3_BN;
+    const int swz = h16_swizzle(mt * nt);
+    const int tile_n = swz % nt, tile_m = swz / nt;
+    const int m0 = tile_m * S3_BM, n0 = tile_n * S3_BN;
+    const int ktiles = (K + S3_BK - 1) / S3_BK;
+    const int per = (ktiles + p.splits - 1) / p.splits;
+    const int kt_beg = blockIdx.y * per;
+    const int kt_end = min(ktiles, kt_beg + per);
+
+    f32x16 acc[TM][TN];
+    static_for<TM * TN>([&](auto IJ) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[decltype(IJ)::value / TN][decltype(IJ)::value % TN][r] = 0.f;
+    });
+
+    const bool do_colsum = !AK && p.colsum_a != nullptr && tile_n == 0;
+    float asum[4] = {0.f, 0.f, 0.f, 0.f};    // row-contiguous A: sums over k of this thread's 4 rows
+    // staging: 2 float4 per thread, operand and K tile
+    //   K-contiguous  : k quad kq = tid & 3, rows (tid >> 2) + 64 q
+    //   row-contiguous: k pair kp = tid & 7 (k = 2 kp + q), row quad tid >> 3
+    const int kq = tid & 3, kp = tid & 7;
+    if (kt_beg < kt_end) {
+        float4 sa[S3_D][2], sb[S3_D][2];
+        const int Kc4 = (K - 1) & ~3, Kc1 = K - 1;
+        const float* pa[2];
+        const float* pb[2];
+        if constexpr (AK) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) pa[q] = p.A + (int64_t)min(m0 + (tid >> 2) + 64 * q, M - 1) * p.lda;
+        } else {
+            pa[0] = p.A + min(m0 + 4 * (tid >> 3), (M - 1) & ~3);
+        }
+        if constexpr (BKC) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) pb[q] = p.B + (int64_t)min(n0 + (tid >> 2) + 64 * q, N - 1) * p.ldb;
+        } else {
+            pb[0] = p.B + min(n0 + 4 * (tid >> 3), (N - 1) & ~3);
+        }
+        // unconditional loads from clamped addresses (tiles past the end re-read valid elements)
+        auto load_a = [&](float4& dst, int q, int kt) {
+            const int k0 = kt * S3_BK;
+            if constexpr (AK) {
+                dst = *reinterpret_cast<const float4*>(pa[q] + min(k0 + 4 * kq, Kc4));
+            } else {
+                const int k = min(k0 + 2 * kp + q, Kc1);
+                const uint32_t row = p.idx_a ? (uint32_t)p.idx_a[k] : (uint32_t)k;
+                dst = *reinterpret_cast<const float4*>(pa[0] + row * (uint32_t)p.lda);
+            }
+        };
+        auto load_b = [&](float4& dst, int q, int kt) {
+            const int k0 = kt * S3_BK;
+            if constexpr (BKC) {
+                dst = *reinterpret_cast<const float4*>(pb[q] + min(k0 + 4 * kq, Kc4));
+            } else {
+                const int k = min(k0 + 2 * kp + q, Kc1);
+                const uint32_t row = p.idx_b ? (uint32_t)p.idx_b[k] : (uint32_t)k;
+                dst = *reinterpret_cast<const float4*>(pb[0] + row * (uint32_t)p.ldb);
+            }
+        };
+        // K tail: the A elements beyond K are zeroed (their B partners are finite re-reads)
+        auto fix_tail = [&](float4 (&x)[2], int kt) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bool z = AK ? (kt * S3_BK + 4 * kq >= K) : (kt * S3_BK + 2 * kp + q >= K);
+                if (z) { x[q].x = 0.f; x[q].y = 0.f; x[q].z = 0.f; x[q].w = 0.f; }
+            }
+        };
+        const int li = lane & 31, kg = lane >> 5;
+        const int aoff = (wm * 64 + li) * S3_LD + 8 * kg, boff = 3 * S3_OP + (wn * 64 + li) * S3_LD + 8 * kg;
+        // LDS destinations, halves from the start of an operand's plane 0
+        const int dst_a0 = AK ? (tid >> 2) * S3_LD + 4 * kq : 4 * (tid >> 3) * S3_LD + 2 * kp;
+        const int dst_b0 = BKC ? (tid >> 2) * S3_LD + 4 * kq : 4 * (tid >> 3) * S3_LD + 2 * kp;
+        uint32_t lo[3], hi[3];
+        // One piece of an operand's re-staging (tile in register set x -> LDS planes at `out`):
+        //   K-contiguous   u = 0..7: per float4 q [split x,y | split z,w | three ds_write_b64 | re-load]
+        //   row-contiguous u = 0..9: per micro-tile row e [split (k, k+1) | three ds_write_b32], then
+        //                            the two re-loads; u = 10, 11: nothing
+        auto sub_op = [&](auto ISA, auto U, float4 (&x)[2], unsigned short* out, bool live, int kt_next) {
+            constexpr bool isA = decltype(ISA)::value;
+            constexpr int u = decltype(U)::value;
+            constexpr bool KC = isA ? AK : BKC;
+            auto comp = [](const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
+            unsigned short* dst = out + (isA ? dst_a0 : 3 * S3_OP + dst_b0);
+            if constexpr (KC) {
+                if constexpr (u < 8) {
+                    constexpr int q = u / 4, part = u % 4;
+                    if constexpr (part == 0) split3_pair(x[q].x, x[q].y, lo);
+                    if constexpr (part == 1) split3_pair(x[q].z, x[q].w, hi);
+                    if constexpr (part == 2) {
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            *reinterpret_cast<u32x2*>(dst + q * 64 * S3_LD + t * S3_OP) = u32x2{lo[t], hi[t]};
+                    }
+                    if constexpr (part == 3) { if constexpr (isA) load_a(x[q], q, kt_next); else load_b(x[q], q, kt_next); }
+                }
+            } else if constexpr (u < 8) {
+                constexpr int e = u / 2, part = u % 2;
+                if constexpr (part == 0) {
+                    split3_pair(comp(x[0], e), comp(x[1], e), lo);
+                    if constexpr (isA) {     // bias gradient: exact fp32 sums of the deltas, branch-free
+                        const float v = comp(x[0], e) + comp(x[1], e);
+                        asum[e] += (live && do_colsum) ? v : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) *reinterpret_cast<uint32_t*>(dst + e * S3_LD + t * S3_OP) = lo[t];
+                }
+            } else if constexpr (u < 10) {
+                if constexpr (isA) load_a(x[u - 8], u - 8, kt_next); else load_b(x[u - 8], u - 8, kt_next);
+            }
+        };
+        using TrueT = std::integral_constant<bool, true>;
+        using FalseT = std::integral_constant<bool, false>;
+        // One pipelined step (relative tile index j = kt - kt_beg, R = j % S3_D compile-time): the 24
+        // MFMAs of tile j from LDS buffer j & 1; slots 0..11 re-stage the A operand of tile j + 1 (register
+        // set (j + 1) % S3_D -> buffer (j + 1) & 1) and re-load the set with tile j + 1 + S3_D, slots
+        // 12..23 the B operand.  Fragment = one ds_read_b128: lane l holds row l & 31, 8 consecutive k at
+        // 8 * (l >> 5).
+        auto step = [&](auto RR, int kt) {
+            constexpr int R = decltype(RR)::value, P = R & 1, Q = (R + 1) % S3_D;
+            if ((kt + 2) * S3_BK > K && kt + 1 < kt_end) fix_tail(sa[Q], kt + 1);   // uniform, last tile only
+            const unsigned short* base = hsmem + P * S3_BUF;
+            unsigned short* out = hsmem + (P ^ 1) * S3_BUF;
+            const bool live = kt + 1 < kt_end;
+            b16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[t][i] = *reinterpret_cast<const b16x8*>(base + aoff + t * S3_OP + i * 32 * S3_LD);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[t][j] = *reinterpret_cast<const b16x8*>(base + boff + t * S3_OP + j * 32 * S3_LD);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<24>([&](auto SI) {
+                constexpr int sl = decltype(SI)::value;
+                constexpr int t = sl / 4, i = (sl % 4) / TN, j = sl % TN;
+                // (A term, B term), smallest products first: x1y3, x3y1, x2y2, x1y2, x2y1, x1y1
+                constexpr int ta = t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 1 : t == 3 ? 0 : t == 4 ? 1 : 0;
+                constexpr int tb = t == 0 ? 2 : t == 1 ? 0 : t == 2 ? 1 : t == 3 ? 1 : t == 4 ? 0 : 0;
+                // operands swapped: the accumulator tile is the transpose of the output block (h16_epilogue)
+                acc[i][j] = HT::mfma(bf[tb][j], af[ta][i], acc[i][j]);
+                if constexpr (sl < 12) sub_op(TrueT{}, std::integral_constant<int, sl>{}, sa[Q], out, live, kt + 1 + S3_D);
+                else sub_op(FalseT{}, std::integral_constant<int, sl - 12>{}, sb[Q], out, live, kt + 1 + S3_D);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            __syncthreads();
+        };
+
+        // prologue: tiles 0 .. S3_D-1 into their register sets, tile 0 into LDS buffer 0 (its set is
+        // re-loaded with tile S3_D)
+        static_for<S3_D>([&](auto J) {
+            constexpr int jj = decltype(J)::value;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { load_a(sa[jj][q], q, kt_beg + jj); load_b(sb[jj][q], q, kt_beg + jj); }
+        });
+        if ((kt_beg + 1) * S3_BK > K) fix_tail(sa[0], kt_beg);
+        static_for<12>([&](auto U) { sub_op(TrueT{}, U, sa[0], hsmem, true, kt_beg + S3_D); });
+        static_for<12>([&](auto U) { sub_op(FalseT{}, U, sb[0], hsmem, true, kt_beg + S3_D); });
+        __syncthreads();
+        for (int kt = kt_beg; kt < kt_end; kt += S3_D) {
+            step(std::integral_constant<int, 0>{}, kt);
+            if (kt + 1 < kt_end) step(std::integral_constant<int, 1>{}, kt + 1);
+            if (kt + 2 < kt_end) step(std::integral_constant<int, 2>{}, kt + 2);
+            if (kt + 3 < kt_end) step(std::integral_constant<int, 3>{}, kt + 3);
+        }
+    }
+    if constexpr (!AK) {
+        if (do_colsum) h16_colsum_out<8>(p, asum, m0, tid >> 3, kp);   // block-uniform
+    }
+    h16_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------ host side
+
+int64_t gemm_s3_plan_splits(int M, int N, int K, int* splits)
+{
+    const int mt = (M + S3_BM - 1) / S3_BM, nt = (N + S3_BN - 1) / S3_BN;
+    const int ktiles = (K + 63) / 64;
+    int s = 1;
+    // fill whole rounds of 256 CUs x 2 resident blocks, >= 4 x 64 k per split
+    const int tiles = mt * nt, slots = 512;
+    if (tiles < 2 * slots) {
+        double best = 0.0;
+        const int smax = std::min(64, std::max(1, ktiles / 4));
+        for (int c = 1; c <= smax; ++c) {
+            const int blocks = tiles * c;
+            const int rounds = (blocks + slots - 1) / slots;
+            const double eff = (double)blocks / ((double)rounds * slots) - 0.002 * c;
+            if (eff > best + 1e-9) { best = eff; s = c; }
+        }
+    }
+    *splits = s;
+    return s > 1 ? (int64_t)s * M * (N + 1) : 0;
+}
+
+int launch_gemm_s3(const GemmArgs& a, hipStream_t stream)
+{
+    const int mt = (a.M + S3_BM - 1) / S3_BM, nt = (a.N + S3_BN - 1) / S3_BN;
+    dim3 grid(mt * nt, a.splits), block(S3_NT);
+    void (*kern)(GemmArgs) = nullptr;
+    constexpr size_t smem = sizeof(unsigned short) * 2 * S3_BUF;
+    if (a.a_kcontig && a.b_kcontig) kern = gemm_s3_kernel<true, true>;
+    else if (a.a_kcontig && !a.b_kcontig) kern = gemm_s3_kernel<true, false>;
+    else if (!a.a_kcontig && a.b_kcontig) kern = gemm_s3_kernel<false, true>;
+    else kern = gemm_s3_kernel<false, false>;
+    {
+        static std::mutex mu;
+        static std::set<const void*> done;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!done.count(reinterpret_cast<const void*>(kern))) {
+            SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            done.insert(reinterpret_cast<const void*>(kern));
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, a);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+}  // namespace sctc

@@ -31,7 +31,7 @@ class TensorStack(list):
 class NNet:
 
     def __init__(self, inputDim, outputDim, layerSize, numLayers, maxBatch,
-                 train=True, temporalLayer=-1, reg=0.0, maxUtts=1, fp16=False):
+                 train=True, temporalLayer=-1, reg=0.0, maxUtts=1, fp16=False, gemm=None):
         cm.cublas_init()                      # brnnet.py:13 (fails here without the library)
         self.outputDim = outputDim
         self.inputDim = inputDim
@@ -43,6 +43,15 @@ class NNet:
         # extension (BASELINE configs[4] "fp16 acts / fp32 alpha-beta"): 16-bit operands on the
         # matrix cores, fp32 accumulation; False = the reference's fp32 arithmetic
         self.fp16 = bool(fp16)
+        # extension: which matrix-core instruction carries the fp32 time-batched contractions.
+        # None / "f32": v_mfma_f32_32x32x2_f32 (the reference's fp32 fma arithmetic);
+        # "bf16x3": every fp32 operand split exactly into three bfloat16 terms, six cross products
+        # on the bfloat16 matrix cores, fp32 accumulation -- fp32-accurate, same tolerances
+        if gemm not in (None, "f32", "bf16x3"):
+            raise ValueError("gemm must be None, 'f32' or 'bf16x3'")
+        if gemm == "bf16x3" and self.fp16:
+            raise ValueError("gemm='bf16x3' is an fp32 mode; it excludes fp16=True")
+        self.gemm = gemm or "f32"
         self.train = train
         self.reg = reg
         self.regcost = 0.0
@@ -64,7 +73,8 @@ class NNet:
                                 self.temporalLayer, int(self.maxBatch) * int(self.maxUtts),
                                 int(self.maxUtts), float(self.maxAct) if self.maxAct else 0.0,
                                 float(self.reg), 1 if self.train else 0,
-                                _sctc.F16 if self.fp16 else _sctc.F32)
+                                _sctc.F16 if self.fp16 else
+                                (_sctc.BF16X3 if self.gemm == "bf16x3" else _sctc.F32))
 
     def _allocate(self):
         torch = _sctc.require_gpu()

@@ -318,7 +318,76 @@ def sec_gemmh():
               % (tag, M, N, K, res[0][0], res[0][1], res[1][0], res[1][1], byts / res[1][0] / 1e9, res[2][0], res[2][1]))
 
 
-def sec_brnn(cfgname="cfg3", B=32, sync=None, fp16=False):
+def sec_gemmx3():
+    """the three-term bfloat16 split GEMM (sctc_gemm_h16, SCTC_BF16X3): speed at the cfg-3 shapes and
+    error against a float64 product, next to the fp32 matrix-core GEMM"""
+    L = _sctc.lib()
+    ws = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+
+    def call(dt, a, b, c, M, N, K, akc, bkc):
+        if dt is None:
+            rc = L.sctc_gemm_f32(a.data_ptr(), a.shape[1], akc, b.data_ptr(), b.shape[1], bkc,
+                                 c.data_ptr(), N, M, N, K, None, 0, ws.data_ptr(), ws.numel(), None)
+        else:
+            rc = L.sctc_gemm_h16(a.data_ptr(), a.shape[1], akc, b.data_ptr(), b.shape[1], bkc,
+                                 c.data_ptr(), N, M, N, K, None, 0, dt, ws.data_ptr(), ws.numel(), None)
+        assert rc == 0, L.sctc_last_error()
+    for (M, N, K, akc, bkc, tag) in ((32000, 1824, 1824, 1, 1, "fwd NT"), (32000, 1824, 1824, 1, 0, "dgrad NN"),
+                                     (1824, 1824, 32000, 0, 0, "wgrad TN"), (32000, 1824, 484, 1, 1, "fwd L1"),
+                                     (64000, 2048, 2048, 1, 1, "fwd NT cfg5"), (8192, 8192, 8192, 1, 1, "square 8k")):
+        a = torch.randn((M, K) if akc else (K, M), device="cuda")
+        b = torch.randn((N, K) if bkc else (K, N), device="cuda")
+        c = torch.empty((M, N), device="cuda")
+        res = []
+        for dt in (None, _sctc.BF16X3):
+            ms = timed(lambda: call(dt, a, b, c, M, N, K, akc, bkc), iters=5, warm=2)
+            res.append((ms, 2.0 * M * N * K / ms / 1e9))
+        print("%-12s M=%d N=%d K=%d: f32 %.3f ms %.0f TF | bf16x3 %.3f ms %.0f TF (x%.2f)"
+              % (tag, M, N, K, res[0][0], res[0][1], res[1][0], res[1][1], res[0][0] / res[1][0]))
+        del a, b, c
+    # accuracy: |C - C64| relative to sum_k |a||b| (the bound both error models are stated in)
+    for (M, N, K, akc, bkc, scale) in ((1024, 512, 2048, 1, 1, "randn"), (512, 1024, 4096, 0, 0, "randn"),
+                                       (1024, 512, 2048, 1, 0, "lognormal")):
+        a = torch.randn((M, K) if akc else (K, M), device="cuda")
+        b = torch.randn((N, K) if bkc else (K, N), device="cuda")
+        if scale == "lognormal":
+            a = a * torch.exp(4 * torch.randn_like(a))
+            b = b * torch.exp(4 * torch.randn_like(b))
+        A64 = (a if akc else a.t()).double()
+        B64 = (b if bkc else b.t()).double()
+        ref = A64 @ B64.t()
+        bound = A64.abs() @ B64.abs().t()
+        out = []
+        for dt in (None, _sctc.BF16X3, _sctc.BF16):
+            c = torch.empty((M, N), device="cuda")
+            call(dt, a, b, c, M, N, K, akc, bkc)
+            e = ((c.double() - ref).abs() / bound)
+            out.append((e.max().item(), e.mean().item()))
+        print("error / sum|a||b| (%s, K=%d, %s%s): f32 mfma max %.2e mean %.2e | bf16x3 max %.2e mean %.2e | "
+              "bf16 (one term) max %.2e mean %.2e" % (scale, K, "N" if akc else "T", "T" if bkc else "N",
+                                                      out[0][0], out[0][1], out[1][0], out[1][1], out[2][0], out[2][1]))
+
+
+def sec_gemmx3t():
+    """timing only (kernel-variant experiments via SCTC_LIB_PATH)"""
+    L = _sctc.lib()
+    ws = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+    out = []
+    for (M, N, K, akc, bkc, tag) in ((64000, 2048, 2048, 1, 1, "fwdNT"), (2048, 2048, 64000, 0, 0, "wgradTN")):
+        a = torch.randn((M, K) if akc else (K, M), device="cuda")
+        b = torch.randn((N, K) if bkc else (K, N), device="cuda")
+        c = torch.empty((M, N), device="cuda")
+
+        def run():
+            rc = L.sctc_gemm_h16(a.data_ptr(), a.shape[1], akc, b.data_ptr(), b.shape[1], bkc,
+                                 c.data_ptr(), N, M, N, K, None, 0, _sctc.BF16X3, ws.data_ptr(), ws.numel(), None)
+            assert rc == 0, L.sctc_last_error()
+        ms = timed(run, iters=5, warm=2)
+        out.append("%s %.3f ms %.0f TF" % (tag, ms, 2.0 * M * N * K / ms / 1e9))
+    print(os.environ.get("SCTC_LIB_PATH", "default"), "|", " | ".join(out))
+
+
+def sec_brnn(cfgname="cfg3", B=32, sync=None, fp16=False, gemm=None):
     from nnets import brnnet
     cfgs = {"cfg1": (615, 28, 512, 2, 1, 200, 20), "cfg2": (943, 62, 1024, 3, 2, 300, 30),
             "cfg3": (483, 33, 1824, 5, 3, 1000, 100), "cfg4": (615, 33, 1824, 5, 3, 2000, 200),
@@ -327,7 +396,7 @@ def sec_brnn(cfgname="cfg3", B=32, sync=None, fp16=False):
     if sync is not None:
         os.environ["SCTC_REC_SYNC"] = str(sync)
     np.random.seed(0)
-    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B, fp16=fp16)
+    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B, fp16=fp16, gemm=gemm)
     net.initParams()
     rs = np.random.RandomState(1)
     feats = torch.randn(B * T, D, device="cuda")
@@ -342,7 +411,7 @@ def sec_brnn(cfgname="cfg3", B=32, sync=None, fp16=False):
     c, s = run()
     torch.cuda.synchronize()
     print("%s%s B=%d sync=%s first call %.1f ms; cost[0]=%.4f skip=%d" %
-          (cfgname, " fp16" if fp16 else "", B, os.environ.get("SCTC_REC_SYNC", "0"), (time.time() - t0) * 1e3, c[0], s.sum()))
+          (cfgname, " fp16" if fp16 else (" " + gemm if gemm else ""), B, os.environ.get("SCTC_REC_SYNC", "0"), (time.time() - t0) * 1e3, c[0], s.sum()))
     ms = timed(lambda: run(), iters=3, warm=1)
     tot, gm, rc = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
     mb, keep = net._minibatch(feats, Ts, labels)
@@ -411,7 +480,9 @@ def main():
              "brnn4": lambda: sec_brnn("cfg4", 32, None),
              "brnn5": lambda: sec_brnn("cfg5", 1, None), "brnn5b": lambda: sec_brnn("cfg5", 8, None),
              "brnn5h": lambda: sec_brnn("cfg5", 1, None, True), "brnn5bh": lambda: sec_brnn("cfg5", 8, None, True),
-             "brnn3h": lambda: sec_brnn("cfg3", 32, None, True), "gemmh": sec_gemmh,
+             "brnn3h": lambda: sec_brnn("cfg3", 32, None, True), "gemmh": sec_gemmh, "gemmx3": sec_gemmx3, "gemmx3t": sec_gemmx3t,
+             "brnn3x": lambda: sec_brnn("cfg3", 32, None, False, "bf16x3"), "brnn4x": lambda: sec_brnn("cfg4", 32, None, False, "bf16x3"),
+             "brnn2x": lambda: sec_brnn("cfg2", 1, None, False, "bf16x3"),
              "brnn2": lambda: sec_brnn("cfg2", 1, None), "brnnB": lambda: [sec_brnn("cfg3", b, None) for b in (1, 2, 4, 8, 16, 32)], "brnn1u": lambda: sec_brnn("cfg3", 1, None)}
     for name in want:
         print("==== %s" % name, flush=True)

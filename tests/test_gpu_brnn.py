@@ -39,10 +39,10 @@ def host_stack(params):
     return st
 
 
-def make_net(brnnet, dims, params, maxUtts=1, reg=0.0, max_act=20.0, train=True, maxBatch=None):
+def make_net(brnnet, dims, params, maxUtts=1, reg=0.0, max_act=20.0, train=True, maxBatch=None, gemm=None):
     D, A, H, NL, TL, T = dims
     net = brnnet.NNet(D, A, H, NL, maxBatch or T, train=train, temporalLayer=TL, reg=reg,
-                      maxUtts=maxUtts)
+                      maxUtts=maxUtts, gemm=gemm)
     net.maxAct = max_act
     net.setParams(host_stack(params))
     return net

@@ -88,6 +88,18 @@ def test_cfg3_minibatch32_vs_oracle(mods):
     worst = {k: rel(got[k], want[k]) for k in want}
     print("cfg3 B=32 gradient rel-norm errors:", {k: "%.1e" % v for k, v in worst.items()})
     assert within_tol(worst), worst
+    # the same workload with the contractions on the bfloat16 matrix cores (three-term split, fp32-
+    # accurate: NNet(..., gemm="bf16x3")) -- same oracle, same tolerances
+    net3 = make_net(brnnet, (D, A, H, NL, TL, T), params, maxUtts=B, maxBatch=T, gemm="bf16x3")
+    costs3, _, skips3 = net3.costAndGradBatch(datas, labs)
+    assert not skips3.any()
+    np.testing.assert_allclose(costs3, c_ref, rtol=1e-4)
+    got3 = tensors(net3, NL)
+    worst3 = {k: rel(got3[k], want[k]) for k in want}
+    print("cfg3 B=32 bf16x3: worst cost rel err %.2e; gradient rel-norm errors:" % np.max(np.abs(costs3 - c_ref) / c_ref),
+          {k: "%.1e" % v for k, v in worst3.items()})
+    assert within_tol(worst3), worst3
+    del net3
     # run-to-run reproducibility at full size (fixed summation order, no arrival-order effects)
     net.costAndGradBatch(datas, labs)
     again = tensors(net, NL)
