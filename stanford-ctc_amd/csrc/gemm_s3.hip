@@ -19,7 +19,15 @@
 // other LDS buffer and requests tile t+5.  The second block of the CU fills the fragment-read and
 // barrier gaps.  History (64000 x 2048 x 2048, fp32 kernel 4.4 ms): un-pipelined, 2 blocks per CU, one
 // LDS buffer 3.45 ms = 2.11 ms without the MFMAs + 1.29 ms of ideal MFMA time, i.e. fully serialised;
-// K tile 32 pipelined with one register set, one block per CU 2.93 ms.
+// K tile 32 pipelined with one register set, one block per CU 2.93 ms; this kernel 2.85 ms = 189 TFLOP/s.
+// s_memtime stamps (-DSCTC_S3_STAMP, tests/gpu_diag.py s3stamp): forward (NT) 2030 shader cycles per step
+// of the two resident blocks against 1536 of matrix-core time -- 76 % busy -- at a shader clock of 1.44 GHz:
+// the kernel is POWER-bound (a register-only loop of this MFMA on random operands sustains 1775 TFLOP/s =
+// 1.7 GHz, tools/valu_rate.hip; with the split's VALU and LDS traffic on top the clock drops further).
+// Delta propagation (NN) 2435 cycles at 1.60 GHz; weight gradient (TN) 3362 cycles at 2.26 GHz: there
+// the 24 ds_write_b32 per step of the transposing re-staging (2-way bank conflicts) stall the waves.
+// Tried for TN and rejected: (4 k) x (2 rows) micro-tiles with conflict-free ds_write_b64 but 8-byte
+// global loads -- 68 instead of 122 TFLOP/s (twice the load instructions; the load path is request-bound).
 #include <algorithm>
 #include <mutex>
 #include <set>
@@ -235,12 +243,24 @@ __global__ __launch_bounds__(S3_NT, 2) void gemm_s3_kernel(GemmArgs p)
         static_for<12>([&](auto U) { sub_op(TrueT{}, U, sa[0], hsmem, true, kt_beg + S3_D); });
         static_for<12>([&](auto U) { sub_op(FalseT{}, U, sb[0], hsmem, true, kt_beg + S3_D); });
         __syncthreads();
+#ifdef SCTC_S3_STAMP
+        uint64_t st_c0 = 0, st_w0 = 0;
+        if (tid == 0) { st_c0 = __builtin_amdgcn_s_memtime(); st_w0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
         for (int kt = kt_beg; kt < kt_end; kt += S3_D) {
             step(std::integral_constant<int, 0>{}, kt);
             if (kt + 1 < kt_end) step(std::integral_constant<int, 1>{}, kt + 1);
             if (kt + 2 < kt_end) step(std::integral_constant<int, 2>{}, kt + 2);
             if (kt + 3 < kt_end) step(std::integral_constant<int, 3>{}, kt + 3);
         }
+#ifdef SCTC_S3_STAMP
+        // diagnostics build (tests/gpu_diag.py s3stamp): shader cycles and 100 MHz wall ticks of the main loop
+        if (tid == 0 && blockIdx.x < 64 && p.splitk_ws && p.splits == 1) {
+            const uint64_t c1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
+            uint32_t* o = reinterpret_cast<uint32_t*>(p.splitk_ws) + 4 * blockIdx.x;
+            o[0] = (uint32_t)(c1 - st_c0); o[1] = (uint32_t)(w1 - st_w0); o[2] = (uint32_t)(kt_end - kt_beg); o[3] = 1;
+        }
+#endif
     }
     if constexpr (!AK) {
         if (do_colsum) h16_colsum_out<8>(p, asum, m0, tid >> 3, kp);   // block-uniform

@@ -387,6 +387,30 @@ def sec_gemmx3t():
     print(os.environ.get("SCTC_LIB_PATH", "default"), "|", " | ".join(out))
 
 
+def sec_s3stamp():
+    """cycles per K-tile step of gemm_s3_kernel and the shader clock under its load (needs a library
+    built with -DSCTC_GEMM_STAMP -DSCTC_S3_STAMP)"""
+    L = _sctc.lib()
+    for (M, N, K, akc, bkc, tag) in ((64000, 2048, 2048, 1, 1, "NT"), (64000, 2048, 2048, 1, 0, "NN"),
+                                     (2048, 2048, 16000, 0, 0, "TN")):
+        a = torch.randn((M, K) if akc else (K, M), device="cuda")
+        b = torch.randn((N, K) if bkc else (K, N), device="cuda")
+        c = torch.empty((M, N), device="cuda")
+        ws = torch.zeros(4096, dtype=torch.int32, device="cuda")
+        for _ in range(3):
+            rc = L.sctc_gemm_h16(a.data_ptr(), a.shape[1], akc, b.data_ptr(), b.shape[1], bkc,
+                                 c.data_ptr(), N, M, N, K, None, 0, _sctc.BF16X3, ws.data_ptr(), 0, None)
+            assert rc == 0, L.sctc_last_error()
+        torch.cuda.synchronize()
+        st = ws.cpu().numpy()[:256].reshape(64, 4).astype(np.int64)
+        st = st[st[:, 3] == 1]
+        cyc = st[:, 0] / st[:, 2]
+        mhz = 100.0 * st[:, 0] / np.maximum(1, st[:, 1])
+        print("gemm_s3 %s: %.0f shader cycles per 24-MFMA step (768 = matrix core saturated by ONE of the two "
+              "resident blocks, 1536 by both), shader clock %.0f MHz (%d blocks stamped)"
+              % (tag, np.median(cyc), np.median(mhz), len(st)))
+
+
 def sec_brnn(cfgname="cfg3", B=32, sync=None, fp16=False, gemm=None):
     from nnets import brnnet
     cfgs = {"cfg1": (615, 28, 512, 2, 1, 200, 20), "cfg2": (943, 62, 1024, 3, 2, 300, 30),
@@ -480,7 +504,7 @@ def main():
              "brnn4": lambda: sec_brnn("cfg4", 32, None),
              "brnn5": lambda: sec_brnn("cfg5", 1, None), "brnn5b": lambda: sec_brnn("cfg5", 8, None),
              "brnn5h": lambda: sec_brnn("cfg5", 1, None, True), "brnn5bh": lambda: sec_brnn("cfg5", 8, None, True),
-             "brnn3h": lambda: sec_brnn("cfg3", 32, None, True), "gemmh": sec_gemmh, "gemmx3": sec_gemmx3, "gemmx3t": sec_gemmx3t,
+             "brnn3h": lambda: sec_brnn("cfg3", 32, None, True), "gemmh": sec_gemmh, "gemmx3": sec_gemmx3, "s3stamp": sec_s3stamp, "gemmx3t": sec_gemmx3t,
              "brnn3x": lambda: sec_brnn("cfg3", 32, None, False, "bf16x3"), "brnn4x": lambda: sec_brnn("cfg4", 32, None, False, "bf16x3"),
              "brnn2x": lambda: sec_brnn("cfg2", 1, None, False, "bf16x3"),
              "brnn2": lambda: sec_brnn("cfg2", 1, None), "brnnB": lambda: [sec_brnn("cfg3", b, None) for b in (1, 2, 4, 8, 16, 32)], "brnn1u": lambda: sec_brnn("cfg3", 1, None)}
