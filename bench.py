@@ -511,8 +511,8 @@ def f32_split_bf16x3(out, torch, cfg, labels, feats, net32):
                           "peak": PEAK_F16_MFMA_TFLOPS / 6.0, "frac": ach / (PEAK_F16_MFMA_TFLOPS / 6.0),
                           "note": "peak = dense bf16 MFMA peak / 6 executed products per algorithmic product; "
                                   "a register-only loop of v_mfma_f32_32x32x16_bf16 on random operands sustains "
-                                  "1775 TFLOP/s (tools/valu_rate.hip), i.e. 296 fp32-equivalent; ds_read_b128 "
-                                  "delivers 64 B/clk per CU, which the 64x64 wave tile needs in full"}}
+                                  "1775 TFLOP/s (tools/valu_rate.hip), i.e. 296 fp32-equivalent; the forward kernel keeps "
+                                  "the matrix cores 76 % busy at a shader clock of 1.44 GHz (power-bound), DESIGN.md 4.1c"}}
     del net
 
 
@@ -557,8 +557,8 @@ def cfg5_fp16(out, torch):
                               "achieved": gm.value / (gemm_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": gm.value / (gemm_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
                               "note": "16-bit shadow copies of activations / deltas / weights are written by "
-                                      "their producers; the kernel is bound by the CU's load-request rate and "
-                                      "ds_read_b128 bandwidth (64 B/clk), not by the matrix pipes"},
+                                      "their producers; the kernel is bound by the CU's operand-load path "
+                                      "(DESIGN.md 4.1b), not by the matrix pipes"},
             "us_per_recurrent_step": (ph["fwd_rec"] + ph["bwd_rec"]) * 1e3 / (2 * (T - 1)),
             "ctc_ms": ph["ctc"]}
         del net

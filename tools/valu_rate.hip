@@ -1,5 +1,6 @@
-// Diagnostics: issue cost (shader cycles per wave-instruction) of the VALU instructions the
-// three-term bfloat16 split (gemm_s3.hip) is made of, one wave per SIMD, no memory traffic.
+// Diagnostics: the sustained rate of v_mfma_f32_32x32x16_bf16 on constant and on random operands
+// (register-only loops, 1..3 waves per SIMD: the clock follows the power draw), and the issue cost of the
+// VALU instructions the three-term bfloat16 split (gemm_s3.hip) is made of.
 //   hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o gpurun_out/valu_rate && gpurun_out/valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -122,53 +123,9 @@ static void run_mfma(int waves_per_simd, int random)
     hipFree(out);
 }
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// LDS read throughput of ds_read_b128, 8 waves per CU (2 per SIMD), STRIDE = byte distance of the rows
-// that lanes 0..31 read (lanes 32..63 read 16 bytes further): 16 = linear, 48 / 80 = the fragment
-// layouts of gemm_s3.hip / gemm_h16.hip
-template <int STRIDE>
-__global__ __launch_bounds__(256) void lds_read_kernel(float* out, int iters)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    for (int i = threadIdx.x; i < 160 * STRIDE / 4 + 64; i += 256) reinterpret_cast<uint32_t*>(sm)[i] = i * 2654435761u;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned char* base = sm + ((lane & 31) + 32 * (wave & 3)) * STRIDE + 16 * (lane >> 5);
-    u32x4 acc = {0u, 0u, 0u, 0u};
-    for (int i = 0; i < iters; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const u32x4 v = *reinterpret_cast<const volatile u32x4*>(base + (r & 1) * 32 * 0);
-            acc ^= v;
-        }
-    }
-    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345u) out[0] = 1.f;
-}
-
-template <int STRIDE>
-static void run_lds()
-{
-    float* out; hipMalloc(&out, 64);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const int blocks = 256 * 2, iters = 20000;
-    float ms = 0.f;
-    for (int rep = 0; rep < 2; ++rep) {
-        hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(lds_read_kernel<STRIDE>, dim3(blocks), dim3(256), 160 * STRIDE + 256, 0, out, iters);
-        hipEventRecord(e1, 0);
-        hipDeviceSynchronize();
-        hipEventElapsedTime(&ms, e0, e1);
-    }
-    const double bytes = (double)blocks * 256 * iters * 16.0 * 16.0;
-    printf("ds_read_b128, row stride %3d B, 2 blocks x 4 waves per CU: %.1f TB/s = %.1f B/ns per CU (%.1f ms)\n", STRIDE,
-           bytes / (ms * 1e-3) / 1e12, bytes / 256 / (ms * 1e6), ms);
-    hipFree(out);
-}
-
 int main()
 {
-    run_lds<16>(); run_lds<48>(); run_lds<80>(); run_lds<144>();
+
     run_mfma(1, 0); run_mfma(1, 1); run_mfma(2, 1); run_mfma(3, 1);
     run<0>("v_cvt_pk_bf16_f32 (+shift,+fma)", 12);
     run<1>("v_pk_add_f32", 4);
