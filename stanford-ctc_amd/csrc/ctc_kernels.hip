@@ -257,13 +257,21 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
     // workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the
     // lattice-row stores to HBM (vmcnt) in every frame
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // W > 1: ONE workgroup barrier per frame.  Before it every wave publishes its band-sum partial and
+    // its last state's UNNORMALISED value n[K-1]; after it every wave knows the frame's c (and r = 1/c),
+    // and the next frame's neighbour state of lane 0 is bnd * r -- the very multiplication the owning
+    // wave performs, so the lattice is bit-identical to the two-barrier schedule this replaces (publish
+    // the normalised boundary after the sum, meet again at the start of the next frame: 1.08 us per
+    // frame at T = 8000 / U = 800).  Slots alternate by frame parity: a wave that races ahead writes the
+    // other slot, and cannot reach this one again before everybody has passed the next barrier.
     // sum over all states of the block, identical in every lane (fixed order)
-    auto block_sum = [&](R loc, int tau) -> R {
+    auto block_sum = [&](R loc, R last_unnorm, int tau) -> R {
         const R ws = wave_sum(loc);
         if constexpr (W == 1) {
             return ws;
         } else {
             if (lane == 0) part[tau & 1][wave] = ws;
+            if (lane == 63) bnd[tau & 1][wave] = last_unnorm;
             lds_barrier();
             R c = part[tau & 1][0];
 #pragma unroll
@@ -271,20 +279,21 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
             return c;
         }
     };
-    // last state of global lane gl - 1 as of the previous frame (all threads call, start of a frame)
-    auto shift_in = [&](const R (&v)[K], int tau) -> R {
+    // frames without a rescale (lazy schedule): the boundary state alone
+    auto publish = [&](R last, int tau) {
+        if constexpr (W > 1) {
+            if (lane == 63) bnd[tau & 1][wave] = last;
+            lds_barrier();
+        }
+    };
+    // last state of global lane gl - 1 as of the previous frame (all threads call, start of a frame);
+    // rprev = the factor the previous frame's row was scaled with (1 if it was not)
+    auto shift_in = [&](const R (&v)[K], int tau, R rprev) -> R {
         R prev = lane_shr1(v[K - 1]);
         if constexpr (W > 1) {
-            lds_barrier();
-            if (lane == 0 && wave > 0) prev = bnd[(tau - 1) & 1][wave - 1];
+            if (lane == 0 && wave > 0) prev = bnd[(tau - 1) & 1][wave - 1] * rprev;
         }
         return prev;
-    };
-    // publish this wave's last state once a frame's row is final (all threads call)
-    auto shift_out = [&](const R (&v)[K], int tau) {
-        if constexpr (W > 1) {
-            if (lane == 63) bnd[tau & 1][wave] = v[K - 1];
-        }
     };
 
     R a[K];
@@ -295,6 +304,7 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
     R rslot = (R)1;    // applied scale factors are parked one per lane and folded 64 at a time
     int nscaled = 0;
     int skip = 0;
+    R rprev = (R)1;    // factor applied to the previous frame's row (uniform)
     // T < U: the band [start,end) is empty at every frame t >= 1 (L >= 2T+2 does not depend
     // on t): the reference divides nothing, takes log(0) = -inf and returns cost +inf with
     // skip False (ctc_fast.pyx:70-76 on an empty range)
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
         const R yb = bcast(y0, blank);
         const R yl = gather(y0, lab[0]);
         if (gl == 0) { a[0] = yb; a[1] = yl; }
-        const R c = block_sum(a[0] + a[1], 0);
+        const R c = block_sum(a[0] + a[1], a[K - 1], 0);
         if (c == (R)0) {
             skip = 1;  // ZeroDivisionError at :45
         } else {
@@ -317,9 +327,9 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
             a[1] *= r;
             if (lane == 0) rslot = r;
             nscaled = 1;
+            rprev = r;
         }
         store_row(0, a);
-        shift_out(a, 0);
     }
 
     if (!skip && empty_band) {
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
                         const int tau = tb + i;
                         if (skip) continue;
                         const R yb = ybv[i];
-                        const R prev_last = shift_in(a, tau);
+                        const R prev_last = shift_in(a, tau, rprev);
                         R n[K];
 #pragma unroll
                         for (int jj = 0; jj < KH; ++jj) {
@@ -380,13 +390,14 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
                             R loc = n[0];
 #pragma unroll
                             for (int j = 1; j < K; ++j) loc += n[j];
-                            const R c = block_sum(loc, tau);
+                            const R c = block_sum(loc, n[K - 1], tau);
                             if (c == (R)0) {
                                 skip = 1;
                             } else {
                                 const R r = (R)1 / c;
 #pragma unroll
                                 for (int j = 0; j < K; ++j) a[j] = n[j] * r;
+                                rprev = r;
                                 if (lane == (nscaled & 63)) rslot = r;
                                 ++nscaled;
                                 if ((nscaled & 63) == 0) {
@@ -395,11 +406,12 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
                                 }
                             }
                         } else {
+                            publish(n[K - 1], tau);
+                            rprev = (R)1;
 #pragma unroll
                             for (int j = 0; j < K; ++j) a[j] = n[j];
                         }
                         if (!skip) store_row(tau, a);
-                        shift_out(a, tau);
                     }
                 }
             } else {
@@ -413,7 +425,7 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
                     const int start = L <= rem ? 0 : L - rem;
                     R yb;
                     if constexpr (PREG) yb = ybv[i]; else yb = bcast(ycur[i], blank);
-                    const R prev_last = shift_in(a, tau);  // state K*gl - 1
+                    const R prev_last = shift_in(a, tau, rprev);  // state K*gl - 1
                     R n[K];
 #pragma unroll
                     for (int jj = 0; jj < KH; ++jj) {
@@ -436,13 +448,14 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
                         R loc = n[0];
 #pragma unroll
                         for (int j = 1; j < K; ++j) loc += n[j];
-                        const R c = block_sum(loc, tau);
+                        const R c = block_sum(loc, n[K - 1], tau);
                         if (c == (R)0) {
                             skip = 1;  // ZeroDivisionError at :75 (band is non-empty here)
                         } else {
                             const R r = (R)1 / c;
 #pragma unroll
                             for (int j = 0; j < K; ++j) a[j] = n[j] * r;
+                            rprev = r;
                             if (lane == (nscaled & 63)) rslot = r;
                             ++nscaled;
                             if ((nscaled & 63) == 0) {
@@ -451,11 +464,12 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
                             }
                         }
                     } else {
+                        publish(n[K - 1], tau);
+                        rprev = (R)1;
 #pragma unroll
                         for (int j = 0; j < K; ++j) a[j] = n[j];
                     }
                     if (!skip) store_row(tau, a);
-                    shift_out(a, tau);
                 }
             }
             }

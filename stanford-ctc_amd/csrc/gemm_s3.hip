@@ -19,15 +19,20 @@
 // other LDS buffer and requests tile t+5.  The second block of the CU fills the fragment-read and
 // barrier gaps.  History (64000 x 2048 x 2048, fp32 kernel 4.4 ms): un-pipelined, 2 blocks per CU, one
 // LDS buffer 3.45 ms = 2.11 ms without the MFMAs + 1.29 ms of ideal MFMA time, i.e. fully serialised;
-// K tile 32 pipelined with one register set, one block per CU 2.93 ms; this kernel 2.85 ms = 189 TFLOP/s.
+// K tile 32 pipelined with one register set, one block per CU 2.93 ms; this kernel 2.81 ms = 191 TFLOP/s.
 // s_memtime stamps (-DSCTC_S3_STAMP, tests/gpu_diag.py s3stamp): forward (NT) 2030 shader cycles per step
 // of the two resident blocks against 1536 of matrix-core time -- 76 % busy -- at a shader clock of 1.44 GHz:
 // the kernel is POWER-bound (a register-only loop of this MFMA on random operands sustains 1775 TFLOP/s =
 // 1.7 GHz, tools/valu_rate.hip; with the split's VALU and LDS traffic on top the clock drops further).
-// Delta propagation (NN) 2435 cycles at 1.60 GHz; weight gradient (TN) 3362 cycles at 2.26 GHz: there
-// the 24 ds_write_b32 per step of the transposing re-staging (2-way bank conflicts) stall the waves.
-// Tried for TN and rejected: (4 k) x (2 rows) micro-tiles with conflict-free ds_write_b64 but 8-byte
-// global loads -- 68 instead of 122 TFLOP/s (twice the load instructions; the load path is request-bound).
+// Two things that were worth more than any schedule (weight gradient 122 -> 162, delta propagation 157 ->
+// 172 TFLOP/s at the cfg-3 shapes): (i) staging registers declared as HIP's float4 were split into
+// scalars and re-assembled with v_mov right after the load -- behind an s_waitcnt vmcnt(0) that drained
+// the whole four-tile prefetch queue once per step; a native ext_vector_type(4) stays one register tuple
+// (check the loop for vmcnt(0) after every change); (ii) the optional row gather's dependent index load
+// costs the same drain, so it is a separate instantiation.  Row-contiguous operands: first (k pair) x
+// (4 rows) micro-tiles written transposed with ds_write_b32 (2-way bank conflicts for any 16-byte-aligned
+// row stride), now a straight [k][m] copy read back with ds_read_b64_tr_b16; (4 k) x (2 rows) micro-tiles
+// with 8-byte global loads ran at 68 TFLOP/s (twice the load instructions).
 #include <algorithm>
 #include <mutex>
 #include <set>
@@ -40,10 +45,25 @@ namespace sctc {
 
 static constexpr int S3_BM = 128, S3_BN = 128, S3_NT = 256, S3_BK = 16, S3_LD = S3_BK + 8;   // 48-byte LDS rows
 static constexpr int S3_D = 4;                       // prefetch distance in K tiles (register sets)
+// Row-contiguous operands ([k][m] in memory: the weight gradient's deltas and activations, the delta
+// propagation's weights) keep that orientation in LDS -- [k][m] with a k-row stride of 160 halves
+// (320 B: the 4 k-rows x 32 B that a 16-lane group of ds_read_b64_tr_b16 touches, and the second group
+// of the same 32-lane half 32 B further, cover the 64 banks once) -- and are turned into K-contiguous
+// MFMA fragments by the hardware transpose read: the 16 lanes of a group supply the addresses of a
+// [4 k][16 m] block, 4 consecutive m each (lane i: k = i / 4, m = 4 (i % 4)), and lane i receives
+// column i's 4 k.  Staging is then the same straight copy as for K-contiguous operands (float4 = 4
+// consecutive m at one k -> one ds_write_b64 per plane, conflict-free).  The transposing WRITE this
+// replaces -- (k pair) x (4 rows) micro-tiles, 24 ds_write_b32 per step with 2-way bank conflicts --
+// held the weight gradient at 122 TFLOP/s (3362 cycles per step) against 168 forward.
+static constexpr int S3_RS = 160;
+typedef __attribute__((address_space(3))) b16x4 lds_b16x4;
 static constexpr int S3_OP = S3_BM * S3_LD;          // halves per operand plane (S3_BM == S3_BN)
 static constexpr int S3_BUF = 6 * S3_OP;             // halves per buffer: A planes 0..2, B planes 0..2
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // staging registers: a native 128-bit tuple (HIP's float4
+                                                            // was split into scalars and re-assembled with v_mov after
+                                                            // the load, each time behind an s_waitcnt vmcnt(0))
 typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
 
 // exact three-term split of two floats; term t of both packed into one dword (element 0 low).
@@ -72,7 +92,11 @@ __device__ __forceinline__ void put4(unsigned short* dst, float x0, float x1, fl
     for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2*>(dst + t * S3_OP) = u32x2{lo[t], hi[t]};
 }
 
-template <bool AK, bool BKC>
+// GATHER: a row-contiguous operand's k rows go through idx_a / idx_b (the recurrent weight gradient of
+// a ragged minibatch pairs frame t with t+-1 through index lists).  The dependent index load costs an
+// s_waitcnt vmcnt(0) per re-load -- it drains the whole prefetch queue -- so the common case is a
+// separate instantiation without it.
+template <bool AK, bool BKC, bool GATHER>
 __global__ __launch_bounds__(S3_NT, 2) void gemm_s3_kernel(GemmArgs p)
 {
     constexpr int TM = 2, TN = 2;
@@ -98,13 +122,13 @@ __global__ __launch_bounds__(S3_NT, 2) void gemm_s3_kernel(GemmArgs p)
     });
 
     const bool do_colsum = !AK && p.colsum_a != nullptr && tile_n == 0;
-    float asum[4] = {0.f, 0.f, 0.f, 0.f};    // row-contiguous A: sums over k of this thread's 4 rows
+    float asum[4] = {0.f, 0.f, 0.f, 0.f};    // row-contiguous A: sums over k of this thread's 4 columns (m)
     // staging: 2 float4 per thread, operand and K tile
-    //   K-contiguous  : k quad kq = tid & 3, rows (tid >> 2) + 64 q
-    //   row-contiguous: k pair kp = tid & 7 (k = 2 kp + q), row quad tid >> 3
-    const int kq = tid & 3, kp = tid & 7;
+    //   K-contiguous  : k quad kq = tid & 3, rows (tid >> 2) + 64 q        (float4 = 4 k of one row)
+    //   row-contiguous: m quad mq = tid & 31, k = (tid >> 5) + 8 q         (float4 = 4 m of one k)
+    const int kq = tid & 3, mq = tid & 31, kr = tid >> 5;
     if (kt_beg < kt_end) {
-        float4 sa[S3_D][2], sb[S3_D][2];
+        f32x4 sa[S3_D][2], sb[S3_D][2];
         const int Kc4 = (K - 1) & ~3, Kc1 = K - 1;
         const float* pa[2];
         const float* pb[2];
@@ -112,85 +136,94 @@ __global__ __launch_bounds__(S3_NT, 2) void gemm_s3_kernel(GemmArgs p)
 #pragma unroll
             for (int q = 0; q < 2; ++q) pa[q] = p.A + (int64_t)min(m0 + (tid >> 2) + 64 * q, M - 1) * p.lda;
         } else {
-            pa[0] = p.A + min(m0 + 4 * (tid >> 3), (M - 1) & ~3);
+            pa[0] = p.A + min(m0 + 4 * mq, (M - 1) & ~3);
         }
         if constexpr (BKC) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) pb[q] = p.B + (int64_t)min(n0 + (tid >> 2) + 64 * q, N - 1) * p.ldb;
         } else {
-            pb[0] = p.B + min(n0 + 4 * (tid >> 3), (N - 1) & ~3);
+            pb[0] = p.B + min(n0 + 4 * mq, (N - 1) & ~3);
         }
         // unconditional loads from clamped addresses (tiles past the end re-read valid elements)
-        auto load_a = [&](float4& dst, int q, int kt) {
+        auto load_a = [&](f32x4& dst, int q, int kt) {
             const int k0 = kt * S3_BK;
             if constexpr (AK) {
-                dst = *reinterpret_cast<const float4*>(pa[q] + min(k0 + 4 * kq, Kc4));
+                dst = *reinterpret_cast<const f32x4*>(pa[q] + min(k0 + 4 * kq, Kc4));
             } else {
-                const int k = min(k0 + 2 * kp + q, Kc1);
-                const uint32_t row = p.idx_a ? (uint32_t)p.idx_a[k] : (uint32_t)k;
-                dst = *reinterpret_cast<const float4*>(pa[0] + row * (uint32_t)p.lda);
+                const int k = min(k0 + kr + 8 * q, Kc1);
+                uint32_t row = (uint32_t)k;
+                if constexpr (GATHER) { if (p.idx_a) row = (uint32_t)p.idx_a[k]; }
+                dst = *reinterpret_cast<const f32x4*>(pa[0] + row * (uint32_t)p.lda);
             }
         };
-        auto load_b = [&](float4& dst, int q, int kt) {
+        auto load_b = [&](f32x4& dst, int q, int kt) {
             const int k0 = kt * S3_BK;
             if constexpr (BKC) {
-                dst = *reinterpret_cast<const float4*>(pb[q] + min(k0 + 4 * kq, Kc4));
+                dst = *reinterpret_cast<const f32x4*>(pb[q] + min(k0 + 4 * kq, Kc4));
             } else {
-                const int k = min(k0 + 2 * kp + q, Kc1);
-                const uint32_t row = p.idx_b ? (uint32_t)p.idx_b[k] : (uint32_t)k;
-                dst = *reinterpret_cast<const float4*>(pb[0] + row * (uint32_t)p.ldb);
+                const int k = min(k0 + kr + 8 * q, Kc1);
+                uint32_t row = (uint32_t)k;
+                if constexpr (GATHER) { if (p.idx_b) row = (uint32_t)p.idx_b[k]; }
+                dst = *reinterpret_cast<const f32x4*>(pb[0] + row * (uint32_t)p.ldb);
             }
         };
         // K tail: the A elements beyond K are zeroed (their B partners are finite re-reads)
-        auto fix_tail = [&](float4 (&x)[2], int kt) {
+        auto fix_tail = [&](f32x4 (&x)[2], int kt) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const bool z = AK ? (kt * S3_BK + 4 * kq >= K) : (kt * S3_BK + 2 * kp + q >= K);
-                if (z) { x[q].x = 0.f; x[q].y = 0.f; x[q].z = 0.f; x[q].w = 0.f; }
+                const bool z = AK ? (kt * S3_BK + 4 * kq >= K) : (kt * S3_BK + kr + 8 * q >= K);
+                if (z) x[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         };
         const int li = lane & 31, kg = lane >> 5;
-        const int aoff = (wm * 64 + li) * S3_LD + 8 * kg, boff = 3 * S3_OP + (wn * 64 + li) * S3_LD + 8 * kg;
-        // LDS destinations, halves from the start of an operand's plane 0
-        const int dst_a0 = AK ? (tid >> 2) * S3_LD + 4 * kq : 4 * (tid >> 3) * S3_LD + 2 * kp;
-        const int dst_b0 = BKC ? (tid >> 2) * S3_LD + 4 * kq : 4 * (tid >> 3) * S3_LD + 2 * kp;
+        // fragment addresses (halves from the start of a buffer; plane t at + t * S3_OP, B planes after A's)
+        //   K-contiguous  : one ds_read_b128, lane l holds row l & 31, 8 consecutive k at 8 * (l >> 5)
+        //   row-contiguous: two ds_read_b64_tr_b16 (k .. k+3 and k+4 .. k+7 of the lane's k half)
+        const int tr_off = (8 * kg + ((lane & 15) >> 2)) * S3_RS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        const int aoff = AK ? (wm * 64 + li) * S3_LD + 8 * kg : tr_off + wm * 64;
+        const int boff = 3 * S3_OP + (BKC ? (wn * 64 + li) * S3_LD + 8 * kg : tr_off + wn * 64);
+        auto frag = [&](auto KC, const unsigned short* base, int off, int tile) -> b16x8 {
+            if constexpr (decltype(KC)::value) {
+                return *reinterpret_cast<const b16x8*>(base + off + tile * 32 * S3_LD);
+            } else {
+                const unsigned short* q = base + off + tile * 32;
+                const b16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b16x4*)q);
+                const b16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b16x4*)(q + 4 * S3_RS));
+                const u32x2 l2 = __builtin_bit_cast(u32x2, lo4), h2 = __builtin_bit_cast(u32x2, hi4);
+                const u32x4 v = {l2[0], l2[1], h2[0], h2[1]};
+                return __builtin_bit_cast(b16x8, v);
+            }
+        };
+        // LDS destinations of the staging registers, halves from the start of an operand's plane 0
+        const int dst_a0 = AK ? (tid >> 2) * S3_LD + 4 * kq : kr * S3_RS + 4 * mq;
+        const int dst_b0 = BKC ? (tid >> 2) * S3_LD + 4 * kq : kr * S3_RS + 4 * mq;
+        constexpr int DA = AK ? 64 * S3_LD : 8 * S3_RS, DB = BKC ? 64 * S3_LD : 8 * S3_RS;
         uint32_t lo[3], hi[3];
-        // One piece of an operand's re-staging (tile in register set x -> LDS planes at `out`):
-        //   K-contiguous   u = 0..7: per float4 q [split x,y | split z,w | three ds_write_b64 | re-load]
-        //   row-contiguous u = 0..9: per micro-tile row e [split (k, k+1) | three ds_write_b32], then
-        //                            the two re-loads; u = 10, 11: nothing
-        auto sub_op = [&](auto ISA, auto U, float4 (&x)[2], unsigned short* out, bool live, int kt_next) {
+        // One piece of an operand's re-staging (tile in register set x -> LDS planes at `out`), u = 0..7:
+        // per float4 q [split x,y | split z,w | three ds_write_b64 | re-load with tile kt_next]
+        auto sub_op = [&](auto ISA, auto U, f32x4 (&x)[2], unsigned short* out, bool live, int kt_next) {
             constexpr bool isA = decltype(ISA)::value;
             constexpr int u = decltype(U)::value;
-            constexpr bool KC = isA ? AK : BKC;
-            auto comp = [](const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
             unsigned short* dst = out + (isA ? dst_a0 : 3 * S3_OP + dst_b0);
-            if constexpr (KC) {
-                if constexpr (u < 8) {
-                    constexpr int q = u / 4, part = u % 4;
-                    if constexpr (part == 0) split3_pair(x[q].x, x[q].y, lo);
-                    if constexpr (part == 1) split3_pair(x[q].z, x[q].w, hi);
-                    if constexpr (part == 2) {
-#pragma unroll
-                        for (int t = 0; t < 3; ++t)
-                            *reinterpret_cast<u32x2*>(dst + q * 64 * S3_LD + t * S3_OP) = u32x2{lo[t], hi[t]};
-                    }
-                    if constexpr (part == 3) { if constexpr (isA) load_a(x[q], q, kt_next); else load_b(x[q], q, kt_next); }
-                }
-            } else if constexpr (u < 8) {
-                constexpr int e = u / 2, part = u % 2;
+            constexpr int D = isA ? DA : DB;
+            if constexpr (u < 8) {
+                constexpr int q = u / 4, part = u % 4;
                 if constexpr (part == 0) {
-                    split3_pair(comp(x[0], e), comp(x[1], e), lo);
-                    if constexpr (isA) {     // bias gradient: exact fp32 sums of the deltas, branch-free
-                        const float v = comp(x[0], e) + comp(x[1], e);
-                        asum[e] += (live && do_colsum) ? v : 0.f;
+                    split3_pair(x[q].x, x[q].y, lo);
+                    if constexpr (isA && !AK) {     // bias gradient: exact fp32 sums of the deltas, branch-free
+                        const bool on = live && do_colsum;
+                        asum[0] += on ? x[q].x : 0.f;
+                        asum[1] += on ? x[q].y : 0.f;
+                        asum[2] += on ? x[q].z : 0.f;
+                        asum[3] += on ? x[q].w : 0.f;
                     }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) *reinterpret_cast<uint32_t*>(dst + e * S3_LD + t * S3_OP) = lo[t];
                 }
-            } else if constexpr (u < 10) {
-                if constexpr (isA) load_a(x[u - 8], u - 8, kt_next); else load_b(x[u - 8], u - 8, kt_next);
+                if constexpr (part == 1) split3_pair(x[q].z, x[q].w, hi);
+                if constexpr (part == 2) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2*>(dst + q * D + t * S3_OP) = u32x2{lo[t], hi[t]};
+                }
+                if constexpr (part == 3) { if constexpr (isA) load_a(x[q], q, kt_next); else load_b(x[q], q, kt_next); }
             }
         };
         using TrueT = std::integral_constant<bool, true>;
@@ -198,8 +231,7 @@ __global__ __launch_bounds__(S3_NT, 2) void gemm_s3_kernel(GemmArgs p)
         // One pipelined step (relative tile index j = kt - kt_beg, R = j % S3_D compile-time): the 24
         // MFMAs of tile j from LDS buffer j & 1; slots 0..11 re-stage the A operand of tile j + 1 (register
         // set (j + 1) % S3_D -> buffer (j + 1) & 1) and re-load the set with tile j + 1 + S3_D, slots
-        // 12..23 the B operand.  Fragment = one ds_read_b128: lane l holds row l & 31, 8 consecutive k at
-        // 8 * (l >> 5).
+        // 12..23 the B operand.
         auto step = [&](auto RR, int kt) {
             constexpr int R = decltype(RR)::value, P = R & 1, Q = (R + 1) % S3_D;
             if ((kt + 2) * S3_BK > K && kt + 1 < kt_end) fix_tail(sa[Q], kt + 1);   // uniform, last tile only
@@ -210,11 +242,9 @@ __global__ __launch_bounds__(S3_NT, 2) void gemm_s3_kernel(GemmArgs p)
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    af[t][i] = *reinterpret_cast<const b16x8*>(base + aoff + t * S3_OP + i * 32 * S3_LD);
+                for (int i = 0; i < TM; ++i) af[t][i] = frag(std::integral_constant<bool, AK>{}, base, aoff + t * S3_OP, i);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    bf[t][j] = *reinterpret_cast<const b16x8*>(base + boff + t * S3_OP + j * 32 * S3_LD);
+                for (int j = 0; j < TN; ++j) bf[t][j] = frag(std::integral_constant<bool, BKC>{}, base, boff + t * S3_OP, j);
             }
             __builtin_amdgcn_sched_barrier(0);
             static_for<24>([&](auto SI) {
@@ -263,7 +293,25 @@ __global__ __launch_bounds__(S3_NT, 2) void gemm_s3_kernel(GemmArgs p)
 #endif
     }
     if constexpr (!AK) {
-        if (do_colsum) h16_colsum_out<8>(p, asum, m0, tid >> 3, kp);   // block-uniform
+        if (do_colsum) {       // block-uniform: the 8 threads that share an m quad (kr = 0..7) add up via LDS
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(hsmem);          // [8][128]
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[kr * 128 + 4 * mq + c] = asum[c];
+            __syncthreads();
+            if (tid < 128) {
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v += red[r * 128 + tid];
+                const int m = m0 + tid;
+                if (m < p.M) {
+                    if (p.splits > 1)
+                        p.splitk_ws[(int64_t)p.splits * p.M * p.N + (int64_t)blockIdx.y * p.M + m] = v;
+                    else
+                        p.colsum_a[m] = p.accumulate ? p.colsum_a[m] + v : v;
+                }
+            }
+        }
     }
     h16_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
@@ -297,10 +345,11 @@ int launch_gemm_s3(const GemmArgs& a, hipStream_t stream)
     dim3 grid(mt * nt, a.splits), block(S3_NT);
     void (*kern)(GemmArgs) = nullptr;
     constexpr size_t smem = sizeof(unsigned short) * 2 * S3_BUF;
-    if (a.a_kcontig && a.b_kcontig) kern = gemm_s3_kernel<true, true>;
-    else if (a.a_kcontig && !a.b_kcontig) kern = gemm_s3_kernel<true, false>;
-    else if (!a.a_kcontig && a.b_kcontig) kern = gemm_s3_kernel<false, true>;
-    else kern = gemm_s3_kernel<false, false>;
+    const bool gather = (a.idx_a && !a.a_kcontig) || (a.idx_b && !a.b_kcontig);
+    if (a.a_kcontig && a.b_kcontig) kern = gemm_s3_kernel<true, true, false>;
+    else if (a.a_kcontig && !a.b_kcontig) kern = gather ? gemm_s3_kernel<true, false, true> : gemm_s3_kernel<true, false, false>;
+    else if (!a.a_kcontig && a.b_kcontig) kern = gather ? gemm_s3_kernel<false, true, true> : gemm_s3_kernel<false, true, false>;
+    else kern = gather ? gemm_s3_kernel<false, false, true> : gemm_s3_kernel<false, false, false>;
     {
         static std::mutex mu;
         static std::set<const void*> done;

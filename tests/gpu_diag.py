@@ -483,6 +483,26 @@ def sec_recdbg(sync=0, B=32):
             print("%s chain %d (%d wgs), us after first wg started step 70:" % (pname, c, len(w)))
             for k in range(6):
                 print("    %-11s min %.2f  median %.2f  max %.2f" % (names6[k], rel[:, k].min(), np.median(rel[:, k]), rel[:, k].max()))
+    # who is slow?  publish time of step 70 by XCD (block b runs on XCD b % 8) and by position in the grid
+    for ps, pname in enumerate(("forward", "bptt")):
+        a = both[ps, 256:].reshape(512, 8)
+        ids = np.nonzero(a[:, 7] != 0)[0]
+        w = a[ids]
+        t0 = w[:, 0].min()
+        pub = (w[:, 5] - t0) * 0.01
+        seen = (w[:, 1] - t0) * 0.01
+        start = (w[:, 0] - t0) * 0.01
+        print("%s: step-70 publish time (us after the first start) by XCD:" % pname,
+              " ".join("%d:%.1f/%.1f" % (x, np.median(pub[ids % 8 == x]), pub[ids % 8 == x].max()) for x in range(8)))
+        order = np.argsort(-pub)[:12]
+        print("   slowest 12 workgroups (block, xcd, chain, start, flags seen, mfma done, published):",
+              "; ".join("%d,%d,%d,%.1f,%.1f,%.1f,%.1f" % (ids[o], ids[o] % 8, w[o, 7] - 1, start[o], seen[o],
+                                                        (w[o, 2] - t0) * 0.01, pub[o]) for o in order))
+        q = np.argsort(ids)
+        dur = (w[:, 5] - w[:, 1]) * 0.01      # flags seen -> published
+        print("   flags-seen -> published duration: median %.2f, p90 %.2f, max %.2f us; by XCD median:" %
+              (np.median(dur), np.percentile(dur, 90), dur.max()),
+              " ".join("%.2f" % np.median(dur[ids % 8 == x]) for x in range(8)))
     names = ["wait", "load+mfma", "lds-reduce", "epilogue", "publish"]
     for ps, pname in enumerate(("forward", "bptt")):
         for w in range(2):
