@@ -175,7 +175,7 @@ def main():
     cfg["B"] = args.batch
     D, A, H, NL, TL, T, U, B = (cfg[k] for k in ("D", "A", "H", "NL", "TL", "T", "U", "B"))
     np.random.seed(0)                       # identical initial weights on every rank
-    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B)
+    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B, gemm="f32")   # the reference's fp32 arithmetic
     net.initParams()
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)

@@ -17,6 +17,8 @@ skip like brnnet.py:185-186).  ``costAndGradBatch`` is the minibatch extension
 import ctypes
 import pickle
 
+import os
+
 import numpy as np
 
 import _sctc
@@ -47,6 +49,8 @@ class NNet:
         # None / "f32": v_mfma_f32_32x32x2_f32 (the reference's fp32 fma arithmetic);
         # "bf16x3": every fp32 operand split exactly into three bfloat16 terms, six cross products
         # on the bfloat16 matrix cores, fp32 accumulation -- fp32-accurate, same tolerances
+        if gemm is None:                      # drop-in switch for unchanged callers (runNNet.py, sgd.py)
+            gemm = os.environ.get("SCTC_GEMM") or None
         if gemm not in (None, "f32", "bf16x3"):
             raise ValueError("gemm must be None, 'f32' or 'bf16x3'")
         if gemm == "bf16x3" and self.fp16:

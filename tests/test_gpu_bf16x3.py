@@ -94,6 +94,25 @@ def test_gemm_bf16x3_all_layouts(mods):
     assert worst3 < max(2.0 * worst32, 2e-7)
 
 
+def test_gemm_bf16x3_odd_k_and_gather(mods):
+    """weight-gradient layout (both operands [k][m]) with K not a multiple of the K tile, of 4 or of 2
+    (a ragged minibatch's frame count), with and without split-K; K = 0 leaves bias / zero"""
+    _sctc, _, _, torch = mods
+    L = _sctc.lib()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    for (M, N, K) in ((128, 128, 777), (260, 132, 1), (132, 388, 17), (1824, 512, 33), (516, 388, 4099), (64, 64, 0)):
+        a = torch.randn((max(K, 1), M + 4), device="cuda")
+        b = torch.randn((max(K, 1), N), device="cuda")
+        for use_ws in (ws, None):
+            c = torch.full((M, N + 4), 7.0, device="cuda")
+            _gemm(L, _sctc, torch, _sctc.BF16X3, a, b, c, M, N, K, 0, 0, None, 0, use_ws)
+            ref = a[:K, :M].double().t() @ b[:K, :N].double()
+            bound = a[:K, :M].double().abs().t() @ b[:K, :N].double().abs() + 1e-30
+            assert float((c[:, N:] - 7.0).abs().max()) == 0.0
+            err = float(((c[:, :N].double() - ref).abs() / bound).max()) if K else float(c[:, :N].abs().max())
+            assert err < 3e-7, (M, N, K, err)
+
+
 def test_gemm_bf16x3_split_is_exact(mods):
     """operands that are exactly representable in ONE or TWO bfloat16 terms give the exact fp32
     product sums: integers up to 2^16 against +-1 -- every partial sum is an integer below 2^24"""
