@@ -93,9 +93,10 @@ __device__ __forceinline__ void put4(unsigned short* dst, float x0, float x1, fl
 }
 
 // GATHER: a row-contiguous operand's k rows go through idx_a / idx_b (the recurrent weight gradient of
-// a ragged minibatch pairs frame t with t+-1 through index lists).  The dependent index load costs an
-// s_waitcnt vmcnt(0) per re-load -- it drains the whole prefetch queue -- so the common case is a
-// separate instantiation without it.
+// a ragged minibatch pairs frame t with t+-1 through index lists).  An index fetched right before its
+// use costs an s_waitcnt vmcnt(0) per re-load -- it drains the whole prefetch queue -- so (i) the common
+// case is a separate instantiation without any index, (ii) the gather variant fetches the index of a
+// staging register's NEXT tile when it issues the current one (tiles are loaded in increasing order).
 template <bool AK, bool BKC, bool GATHER>
 __global__ __launch_bounds__(S3_NT, 2) void gemm_s3_kernel(GemmArgs p)
 {
@@ -144,27 +145,40 @@ __global__ __launch_bounds__(S3_NT, 2) void gemm_s3_kernel(GemmArgs p)
         } else {
             pb[0] = p.B + min(n0 + 4 * mq, (N - 1) & ~3);
         }
-        // unconditional loads from clamped addresses (tiles past the end re-read valid elements)
+        // gather variant: ia[q] / ib[q] = row of the NEXT tile that staging piece q will load
+        int ia[2] = {0, 0}, ib[2] = {0, 0};
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = min(kt_beg * S3_BK + kr + 8 * q, Kc1);
+                ia[q] = (!AK && p.idx_a) ? p.idx_a[k] : k;
+                ib[q] = (!BKC && p.idx_b) ? p.idx_b[k] : k;
+            }
+        }
+        // unconditional loads from clamped addresses (tiles past the end re-read valid elements); every
+        // staging piece q is loaded for consecutive tiles kt_beg, kt_beg + 1, ... in this order
         auto load_a = [&](f32x4& dst, int q, int kt) {
             const int k0 = kt * S3_BK;
             if constexpr (AK) {
                 dst = *reinterpret_cast<const f32x4*>(pa[q] + min(k0 + 4 * kq, Kc4));
+            } else if constexpr (GATHER) {
+                dst = *reinterpret_cast<const f32x4*>(pa[0] + (uint32_t)ia[q] * (uint32_t)p.lda);
+                const int kn = min(k0 + S3_BK + kr + 8 * q, Kc1);
+                ia[q] = p.idx_a ? p.idx_a[kn] : kn;
             } else {
-                const int k = min(k0 + kr + 8 * q, Kc1);
-                uint32_t row = (uint32_t)k;
-                if constexpr (GATHER) { if (p.idx_a) row = (uint32_t)p.idx_a[k]; }
-                dst = *reinterpret_cast<const f32x4*>(pa[0] + row * (uint32_t)p.lda);
+                dst = *reinterpret_cast<const f32x4*>(pa[0] + (uint32_t)min(k0 + kr + 8 * q, Kc1) * (uint32_t)p.lda);
             }
         };
         auto load_b = [&](f32x4& dst, int q, int kt) {
             const int k0 = kt * S3_BK;
             if constexpr (BKC) {
                 dst = *reinterpret_cast<const f32x4*>(pb[q] + min(k0 + 4 * kq, Kc4));
+            } else if constexpr (GATHER) {
+                dst = *reinterpret_cast<const f32x4*>(pb[0] + (uint32_t)ib[q] * (uint32_t)p.ldb);
+                const int kn = min(k0 + S3_BK + kr + 8 * q, Kc1);
+                ib[q] = p.idx_b ? p.idx_b[kn] : kn;
             } else {
-                const int k = min(k0 + kr + 8 * q, Kc1);
-                uint32_t row = (uint32_t)k;
-                if constexpr (GATHER) { if (p.idx_b) row = (uint32_t)p.idx_b[k]; }
-                dst = *reinterpret_cast<const f32x4*>(pb[0] + row * (uint32_t)p.ldb);
+                dst = *reinterpret_cast<const f32x4*>(pb[0] + (uint32_t)min(k0 + kr + 8 * q, Kc1) * (uint32_t)p.ldb);
             }
         };
         // K tail: the A elements beyond K are zeroed (their B partners are finite re-reads)

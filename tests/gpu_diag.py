@@ -387,6 +387,29 @@ def sec_gemmx3t():
     print(os.environ.get("SCTC_LIB_PATH", "default"), "|", " | ".join(out))
 
 
+def sec_ragged3():
+    """ragged minibatch (index-gathered recurrent weight gradient): fp32 vs bf16x3 step time"""
+    from nnets import brnnet
+    D, A, H, NL, TL, T, U, B = 483, 33, 1824, 5, 3, 1000, 100, 32
+    rs = np.random.RandomState(7)
+    Ts = sorted([int(t) for t in rs.randint(T // 2, T + 1, size=B)], reverse=True)
+    feats = torch.randn(sum(Ts), D, device="cuda")
+    labels = [rs.randint(1, A, size=max(1, t // 10)).astype(np.int32) for t in Ts]
+    for gemm in ("f32", "bf16x3"):
+        np.random.seed(0)
+        net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B, gemm=gemm)
+        net.initParams()
+        ms = timed(lambda: net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts), iters=3, warm=1)
+        print("ragged cfg3 B=32 (%d frames) %s: %.2f ms per step -> %.0f frames/s" % (sum(Ts), gemm, ms, sum(Ts) / ms * 1e3))
+        L = _sctc.lib()
+        L.sctc_brnn_set_profiling(net._h, 1)
+        net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+        arr = (ctypes.c_float * 6)()
+        L.sctc_brnn_phase_ms(net._h, arr)
+        print("  phases ms:", ", ".join("%s %.2f" % (n, v) for n, v in zip(PHASES, arr)))
+        del net
+
+
 def sec_s3stamp():
     """cycles per K-tile step of gemm_s3_kernel and the shader clock under its load (needs a library
     built with -DSCTC_GEMM_STAMP -DSCTC_S3_STAMP)"""
@@ -524,7 +547,7 @@ def main():
              "brnn4": lambda: sec_brnn("cfg4", 32, None),
              "brnn5": lambda: sec_brnn("cfg5", 1, None), "brnn5b": lambda: sec_brnn("cfg5", 8, None),
              "brnn5h": lambda: sec_brnn("cfg5", 1, None, True), "brnn5bh": lambda: sec_brnn("cfg5", 8, None, True),
-             "brnn3h": lambda: sec_brnn("cfg3", 32, None, True), "gemmh": sec_gemmh, "gemmx3": sec_gemmx3, "s3stamp": sec_s3stamp, "gemmx3t": sec_gemmx3t,
+             "brnn3h": lambda: sec_brnn("cfg3", 32, None, True), "gemmh": sec_gemmh, "gemmx3": sec_gemmx3, "s3stamp": sec_s3stamp, "ragged3": sec_ragged3, "gemmx3t": sec_gemmx3t,
              "brnn3x": lambda: sec_brnn("cfg3", 32, None, False, "bf16x3"), "brnn4x": lambda: sec_brnn("cfg4", 32, None, False, "bf16x3"),
              "brnn2x": lambda: sec_brnn("cfg2", 1, None, False, "bf16x3"),
              "brnn2": lambda: sec_brnn("cfg2", 1, None), "brnnB": lambda: [sec_brnn("cfg3", b, None) for b in (1, 2, 4, 8, 16, 32)], "brnn1u": lambda: sec_brnn("cfg3", 1, None)}
