@@ -504,6 +504,7 @@ def f32_split_bf16x3(out, torch, cfg, labels, feats, net32):
         "workload": "the headline workload (cfg-3, minibatch %d, HBM-resident features), gemm='bf16x3'" % B,
         "dtype": "f32 operands and results; products as 6 bf16 x bf16 terms of an exact 3-term split, f32 accumulate",
         "value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "phase_ms": ph,
+        "cost_rel_err_vs_float64_oracle": abs(float(c3[0]) - out["cost_check"]["oracle"]) / abs(out["cost_check"]["oracle"]),
         "max_cost_rel_diff_vs_f32_path": float(np.max(np.abs(c3 - c32) / np.abs(c32))),
         "grad_rel_norm_diff_vs_f32_path": gdiff,
         "roofline_gemm": {"bound": "mfma + lds", "kernel": "gemm_s3_kernel",
