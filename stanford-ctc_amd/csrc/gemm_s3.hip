@@ -45,6 +45,10 @@ namespace sctc {
 
 static constexpr int S3_BM = 128, S3_BN = 128, S3_NT = 256, S3_BK = 16, S3_LD = S3_BK + 8;   // 48-byte LDS rows
 static constexpr int S3_D = 4;                       // prefetch distance in K tiles (register sets)
+#ifndef SCTC_S3_GR
+#define SCTC_S3_GR 8
+#endif
+static constexpr int S3_GR = SCTC_S3_GR;             // tile rows per band of the block -> tile order
 // Row-contiguous operands ([k][m] in memory: the weight gradient's deltas and activations, the delta
 // propagation's weights) keep that orientation in LDS -- [k][m] with a k-row stride of 160 halves
 // (320 B: the 4 k-rows x 32 B that a 16-lane group of ds_read_b64_tr_b16 touches, and the second group
@@ -108,8 +112,13 @@ __global__ __launch_bounds__(S3_NT, 2) void gemm_s3_kernel(GemmArgs p)
     const int wm = wave >> 1, wn = wave & 1;
     const int M = p.M, N = p.N, K = p.K;
     const int mt = (M + S3_BM - 1) / S3_BM, nt = (N + S3_BN - 1) / S3_BN;
+    // tile order: an XCD walks consecutive entries of a list that runs through the output in bands of
+    // S3_GR tile rows, column by column inside a band -- its ~64 concurrently resident blocks then cover
+    // about 8 x 8 tiles (8 A panels + 8 B panels in its L2) instead of 4 full rows (4 + nt panels)
     const int swz = h16_swizzle(mt * nt);
-    const int tile_n = swz % nt, tile_m = swz / nt;
+    const int band = swz / (S3_GR * nt), inb = swz - band * (S3_GR * nt);
+    const int rows = min(S3_GR, mt - band * S3_GR);
+    const int tile_m = band * S3_GR + inb % rows, tile_n = inb / rows;
     const int m0 = tile_m * S3_BM, n0 = tile_n * S3_BN;
     const int ktiles = (K + S3_BK - 1) / S3_BK;
     const int per = (ktiles + p.splits - 1) / p.splits;
