@@ -212,14 +212,26 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
     const int A = p.A;
 
     // a frame's probabilities stay in their storage type until they are gathered
-    auto load_frame = [&](int tau, RI (&dst)[NA]) {
-        const int t = dir ? T - 1 - tau : tau;
-        const RI* yr = probs + frame_row(u, p.rowbase, t) * ld;
+    auto load_row = [&](int64_t row, RI (&dst)[NA]) {
+        const RI* yr = probs + row * ld;
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int k = lane + 64 * q;
             dst[q] = k < A ? yr[k] : (RI)0;
         }
+    };
+    auto load_frame = [&](int tau, RI (&dst)[NA]) {
+        const int t = dir ? T - 1 - tau : tau;
+        load_row(frame_row(u, p.rowbase, t), dst);
+    };
+    // Row indices of a whole block of frames with ONE vector load (lane i <- frame tau0 + i, clamped),
+    // fetched a block before they are needed.  Looking rowbase[t] up frame by frame put a dependent
+    // load and an s_waitcnt vmcnt(0) -- which also waits for every lattice-row store in flight -- in
+    // front of each prefetched frame: 1000 of the 1600 shader cycles a frame cost (s_memtime stamps).
+    auto block_rows = [&](int tau0) -> int {
+        const int tau = min(tau0 + lane, T - 1);
+        const int t = dir ? T - 1 - tau : tau;
+        return p.rowbase ? p.rowbase[t] : t;
     };
     auto gather = [&](const RI (&y)[NA], int k) -> R {
         RI out = lane_gather(y[0], k & 63);
@@ -338,14 +350,17 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
         for (int j = 0; j < K; ++j) z[j] = (R)0;
         for (int tau = 1; tau < T; ++tau) store_row(tau, z);
     } else if (!skip && T > 1) {
+        static_assert(PF <= 64, "one lane per frame of a block");
+        int rbv = block_rows(1);
 #pragma unroll
-        for (int i = 0; i < PF; ++i)
-            load_frame(min(1 + i, T - 1), ycur[i]);   // unconditional (clamped): a load behind a
-                                                      // branch is waited for with vmcnt(0) at once
+        for (int i = 0; i < PF; ++i)                  // unconditional (clamped): a load behind a
+            load_row((int64_t)__builtin_amdgcn_readlane(rbv, i) + u.row0, ycur[i]);   // branch is waited for at once
+        rbv = block_rows(1 + PF);
         for (int tb = 1; tb < T && !skip; tb += PF) {
             RI ynxt[PF][NA];
 #pragma unroll
-            for (int i = 0; i < PF; ++i) load_frame(min(tb + PF + i, T - 1), ynxt[i]);
+            for (int i = 0; i < PF; ++i) load_row((int64_t)__builtin_amdgcn_readlane(rbv, i) + u.row0, ynxt[i]);
+            rbv = block_rows(tb + 2 * PF);            // for the next iteration, a block ahead
             // For short label rows the per-state probabilities of the whole block are gathered
             // (ds_bpermute / readlane) before the serial part starts, so that the LDS-crossbar
             // latency is off the recursion's dependency chain.

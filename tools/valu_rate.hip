@@ -123,8 +123,51 @@ static void run_mfma(int waves_per_simd, int random)
     hipFree(out);
 }
 
+// dependent-chain latency (shader cycles per instruction, one wave) of the float64 operations the CTC
+// lattice recursion is made of
+template <int MODE>
+__global__ __launch_bounds__(64) void lat_kernel(double* out, uint64_t* cyc, int iters)
+{
+    double a = 1.0 + threadIdx.x * 1e-3, b = 1.0000001, c = 0.5;
+    const uint64_t t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if constexpr (MODE == 0) a = a + b;
+            else if constexpr (MODE == 1) a = a * b;
+            else if constexpr (MODE == 2) a = __builtin_fma(a, b, c);
+            else if constexpr (MODE == 3) a = 1.0 / a + b;
+            else if constexpr (MODE == 4) {        // one DPP reduction stage: row_shr:1 of both halves + add
+                const int lo = __builtin_amdgcn_update_dpp(0, (int)__double2loint(a), 0x111, 0xf, 0xf, false);
+                const int hi = __builtin_amdgcn_update_dpp(0, (int)__double2hiint(a), 0x111, 0xf, 0xf, false);
+                a = a + __hiloint2double(hi, lo) * 1e-9;
+            }
+        }
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
+    out[threadIdx.x] = a;
+    if (threadIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = w1 - w0; }
+}
+
+template <int MODE>
+static void run_lat(const char* name, int ops)
+{
+    double* out; uint64_t* cyc;
+    hipMalloc(&out, 64 * 8); hipMalloc(&cyc, 16);
+    const int iters = 200000;
+    hipLaunchKernelGGL(lat_kernel<MODE>, dim3(1), dim3(64), 0, 0, out, cyc, iters);
+    hipLaunchKernelGGL(lat_kernel<MODE>, dim3(1), dim3(64), 0, 0, out, cyc, iters);
+    hipDeviceSynchronize();
+    uint64_t h[2]; hipMemcpy(h, cyc, 16, hipMemcpyDeviceToHost);
+    printf("%-44s %7.1f s_memtime ticks = %6.1f ns per dependent step (%d instr per step); ticks run at %.0f MHz\n", name,
+           (double)h[0] / ((double)iters * 16), (double)h[1] * 10.0 / ((double)iters * 16), ops, 100.0 * (double)h[0] / (double)h[1]);
+    hipFree(out); hipFree(cyc);
+}
+
 int main()
 {
+    run_lat<0>("v_add_f64 chain", 1); run_lat<1>("v_mul_f64 chain", 1); run_lat<2>("v_fma_f64 chain", 1);
+    run_lat<3>("1.0 / x + b (IEEE division) chain", 12); run_lat<4>("DPP row_shr + mul + add chain (f64)", 4);
 
     run_mfma(1, 0); run_mfma(1, 1); run_mfma(2, 1); run_mfma(3, 1);
     run<0>("v_cvt_pk_bf16_f32 (+shift,+fma)", 12);
