@@ -1,6 +1,8 @@
 // Diagnostics: the sustained rate of v_mfma_f32_32x32x16_bf16 on constant and on random operands
 // (register-only loops, 1..3 waves per SIMD: the clock follows the power draw), and the issue cost of the
-// VALU instructions the three-term bfloat16 split (gemm_s3.hip) is made of.
+// VALU instructions the three-term bfloat16 split (gemm_s3.hip) is made of, and the dependent-chain
+// latency of the float64 operations of the CTC lattice recursion (add / mul / fma, IEEE division, one
+// DPP reduction stage) with the shader clock they ran at.
 //   hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o gpurun_out/valu_rate && gpurun_out/valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
