@@ -18,10 +18,10 @@
 // A row-panel consecutively (panel stays in that XCD's 4 MiB L2).
 #include "common.h"
 #include "gemm_f32.h"
+#include "gemm_h16_dev.h"     // h16_epilogue: the vectorised epilogue shared with the 16-bit kernels
 
 namespace sctc {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef SCTC_GEMM_BK
 #define SCTC_GEMM_BK 16
@@ -274,7 +274,9 @@ __global__ __launch_bounds__(TileCfg<SHAPE>::NT, TileCfg<SHAPE>::OCC) void gemm_
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        // operands SWAPPED: the accumulator tile is the transpose of the output block
+                        // (lane = output row, 4 consecutive columns per register quad), see h16_epilogue
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j], af[i], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[i] = an[i];
 #pragma unroll
@@ -317,59 +319,9 @@ __global__ __launch_bounds__(TileCfg<SHAPE>::NT, TileCfg<SHAPE>::OCC) void gemm_
         }
     }
 
-    // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool partial = p.splits > 1;
-    float* out = partial ? p.splitk_ws + (int64_t)blockIdx.y * M * N : p.C;
-    const int64_t ldo = partial ? N : p.ldc;
-    // The auxiliary operands (bias / mask / addend / old C) of a 32x32 tile are fetched as one
-    // batch of independent loads before any of them is used: a load-use pair per element would
-    // serialise 64 L2 round trips per thread.
-    const bool has_mask = !partial && p.mask, has_add = !partial && p.addend;
-    const bool has_acc = !partial && p.accumulate;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
-            const int rbase = m0 + wm * (TM * 32) + i * 32 + 4 * (lane >> 5);
-            const bool col_ok = col < N;
-            const int colc = min(col, N - 1);
-            const float bias = (!partial && p.bias) ? p.bias[colc] : 0.f;
-            // two halves of 8 accumulator rows: 24 auxiliary values live at a time instead of 48
-            // (the full-tile version spilled ~70 registers to scratch in every variant)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float mk[8], ad[8], cc[8];
-#pragma unroll
-                for (int r8 = 0; r8 < 8; ++r8) {
-                    const int r = half * 8 + r8;
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    // unconditional loads from clamped addresses (a load behind a per-lane
-                    // condition becomes an exec-mask branch with spills around it); out-of-range
-                    // elements are never stored
-                    const int64_t rc = min(row, M - 1);
-                    mk[r8] = has_mask ? p.mask[rc * p.ldmask + colc] : 1.f;
-                    ad[r8] = has_add ? p.addend[rc * p.ldadd + colc] : 0.f;
-                    cc[r8] = has_acc ? p.C[rc * p.ldc + colc] : 0.f;
-                }
-#pragma unroll
-                for (int r8 = 0; r8 < 8; ++r8) {
-                    const int r = half * 8 + r8;
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (col_ok && row < M) {
-                        float v = acc[i][j][r];
-                        if (!partial) {
-                            v += bias;
-                            if (p.relu) v = fmaxf(v, 0.f);
-                            if (has_mask) v = mk[r8] > 0.f ? v : 0.f;
-                            if (has_add) v += p.add_scale * ad[r8];
-                            if (has_acc) v += cc[r8];
-                        }
-                        out[(int64_t)row * ldo + col] = v;
-                    }
-                }
-            }
-        }
+    // epilogue: bias / relu / mask / addend / accumulate, 16-byte accesses (each lane owns 4 consecutive
+    // columns of its row).  The scalar version this replaces kept ~50 dwords per lane in scratch.
+    h16_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p)
