@@ -319,7 +319,8 @@ def main():
         # the 157.3 TFLOP/s figure assumes 2.4 GHz; register-only MFMA loops with fresh random
         # operands (no LDS / HBM traffic) show what the part sustains under realistic toggling
         probe = (ctypes.c_float * 8)()
-        if L.sctc_probe_mfma(probe, 8, None) == 0:
+        from tools.diag import sctc_diag       # hardware probes: not part of the product library
+        if sctc_diag.lib().sctc_probe_mfma(probe, 8, None) == 0:
             out["roofline"]["sustained_peak"] = float(probe[4])
             out["roofline"]["frac_of_sustained"] = achieved / float(probe[4])
             out["roofline"]["sustained_note"] = ("v_mfma_f32_32x32x2_f32 loops on every SIMD: %.1f TFLOP/s "

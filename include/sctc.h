@@ -29,13 +29,17 @@
 extern "C" {
 #endif
 
-#define SCTC_ABI_VERSION 2
+#define SCTC_ABI_VERSION 3
 
 #define SCTC_OK 0
 #define SCTC_ERR_ARG (-1)       /* bad argument (the reference raises ValueError/AssertionError) */
 #define SCTC_ERR_HIP (-2)       /* HIP runtime error */
 #define SCTC_ERR_WORKSPACE (-3) /* workspace too small */
-#define SCTC_ERR_TIMEOUT (-4)   /* persistent-kernel grid barrier timed out (device not exclusively ours) */
+#define SCTC_ERR_TIMEOUT (-4)   /* a persistent recurrent launch gave up waiting for its peers (device not
+                                   exclusively ours).  The synchronous entry points re-run such a step by
+                                   themselves (device lease, then per-step launches) and only report this
+                                   when they may not (SCTC_FLAG_ACCUMULATE); sctc_brnn_check reports it for
+                                   asynchronous steps */
 #define SCTC_ERR_STATE (-5)
 
 #define SCTC_F32 0
@@ -54,18 +58,16 @@ int sctc_set_device(int device);
 /* compute units / LDS per CU / total memory of the current device (any may be NULL) */
 int sctc_device_info(int* compute_units, int* lds_bytes_per_cu, int64_t* total_mem_bytes,
                      char* name, int name_len);
-/* runs the cross-lane / MFMA fragment-layout probes; 0 = all as expected, else a bitmask */
-int sctc_selftest(void* stream);
-/* diagnostics: hand-off latencies between workgroups on the same / on different XCDs (flag
- * ping-pong per polling-load scope, 1 KiB tagged payload); the one entry point that allocates
- * (and frees) its own scratch.  results_host[10]: partner block ids (same, cross XCD), then
- * microseconds per round trip: same-XCD {sc0, sc1, sc0+sc1}, cross-XCD {sc0, sc1, sc0+sc1},
- * tagged payload {same, cross}; -1 = timed out (e.g. a scope that never observes the store) */
-int sctc_probe_fabric(float* results_host, int32_t n_results, void* stream);
-/* diagnostics: sustained fp32 matrix-pipe rate of register-only MFMA loops on every SIMD:
- * results_host[8] = {TFLOP/s, ms} for v_mfma_f32_32x32x2_f32 and v_mfma_f32_16x16x4_f32 with
- * constant operands, then the same two with fresh random operands per MFMA group */
-int sctc_probe_mfma(float* results_host, int32_t n_results, void* stream);
+/* Shared-device mode.  The reference's per-step launches (brnnet.py:148-152, :215-224) work on a
+ * GPU that other processes use as well; the persistent recurrent kernels that replace them need
+ * every workgroup of a pass resident at once.  With shared-device mode on, each persistent launch
+ * runs under an inter-process lease (flock on a per-device file in /dev/shm), synchronously: two
+ * ranks on one GPU take turns instead of dead-locking each other.  Initial value: environment
+ * variable SCTC_SHARED_DEVICE (the Python mirror sets it when the local ranks outnumber the
+ * visible devices); switched on automatically, for the rest of the process, by the first
+ * SCTC_ERR_TIMEOUT.  One rank per GPU (the default) pays nothing. */
+int sctc_set_shared_device(int32_t on);
+int sctc_shared_device(void);
 
 /* ---- CTC: ctc_fast/ctc-loss/ctc_fast.pyx ------------------------------- */
 
@@ -212,6 +214,12 @@ int sctc_stream_wait_event(void* stream, void* event);
  * SCTC_ERR_TIMEOUT when a persistent recurrent kernel gave up waiting for its peers (results of
  * that call are then meaningless), SCTC_OK otherwise */
 int sctc_brnn_check(sctc_brnn_t h, void* stream);
+/* which recurrence the last step ran (diagnostics / tests): 1 = one persistent launch per pass,
+ * 2 = the same under the device lease, 3 = the non-persistent fallback (one launch per time step;
+ * taken when a persistent grid cannot be co-resident: layer sizes beyond 2048 units, CU masks, a
+ * step re-run after SCTC_ERR_TIMEOUT, SCTC_REC_VARIANT=3), 0 = none yet; *retries = steps of this
+ * handle that were re-run after a timeout.  Any pointer may be NULL. */
+int sctc_brnn_recurrent_path(sctc_brnn_t h, int32_t* forward_path, int32_t* bptt_path, int32_t* retries);
 
 /* NNet(train=False).costAndGrad(data) (brnnet.py:171-173): probs_dev float [sum T][output_dim],
  * caller order, each utterance the reference's (outputDim,T) F-order probs */
@@ -274,15 +282,18 @@ int sctc_nesterov_step(float* w_dev, float* v_dev, const float* g_dev, int64_t n
                        void* stream);
 
 /* Minibatch / data-parallel form of the two calls above with the L2 term applied exactly once:
- * the effective gradient is  e = grad_scale * g + reg * w  (g = SUM of the data gradients over the
- * minibatch, all-reduced over the ranks; grad_scale = 1/n_valid; brnnet.py:197-198 adds reg*W to
- * each utterance's gradient, whose minibatch MEAN is this).
+ * the effective gradient is  e = grad_scale * g + reg * (w + mom * v)  (g = SUM of the data
+ * gradients over the minibatch, all-reduced over the ranks; grad_scale = 1/n_valid;
+ * brnnet.py:197-198 adds reg*W to each utterance's gradient AT THE LOOK-AHEAD POINT w + mom*v
+ * where sgd.py:91-95 evaluates it; w here is the weight after the look-ahead was undone
+ * (sgd.py:97-100), v the velocity before this step's update; v_dev NULL = plain reg*w).
  *   sctc_sumsq_reg:          *out_dev = sum e^2 (float64 accumulation, two deterministic stages)
  *   sctc_nesterov_step_reg:  alph = alpha * min(1, maxGNorm / sqrt(*sumsq_dev));
  *                            v = mom*v - alph*e ;  w += v                                   */
-/*   noreg_ranges_host: n_ranges (<= 32) element ranges [beg, end) of the flat buffers that carry
- *                      NO L2 term -- the biases (brnnet.py:197-200 regularises w only)          */
-int sctc_sumsq_reg(const float* g_dev, const float* w_dev, float grad_scale, float reg, int64_t n,
+/*   noreg_ranges_host: n_ranges (<= 128) ascending, disjoint element ranges [beg, end) of the flat
+ *                      buffers that carry NO L2 term -- the biases (brnnet.py:197-200 regularises w only) */
+int sctc_sumsq_reg(const float* g_dev, const float* w_dev, const float* v_dev, float mom,
+                   float grad_scale, float reg, int64_t n,
                    const int64_t* noreg_ranges_host, int32_t n_ranges, double* out_dev,
                    void* workspace_dev, size_t workspace_bytes, void* stream);
 int sctc_nesterov_step_reg(float* w_dev, float* v_dev, const float* g_dev, int64_t n, float mom,

@@ -56,9 +56,8 @@ PROTOTYPES = {
     "sctc_last_error": (ctypes.c_char_p, []),
     "sctc_set_device": (ctypes.c_int, [ctypes.c_int]),
     "sctc_device_info": (ctypes.c_int, [c_i32p, c_i32p, c_i64p, ctypes.c_char_p, ctypes.c_int]),
-    "sctc_selftest": (ctypes.c_int, [vp]),
-    "sctc_probe_fabric": (ctypes.c_int, [c_f32p, ctypes.c_int32, vp]),
-    "sctc_probe_mfma": (ctypes.c_int, [c_f32p, ctypes.c_int32, vp]),
+    "sctc_set_shared_device": (ctypes.c_int, [ctypes.c_int32]),
+    "sctc_shared_device": (ctypes.c_int, []),
     "sctc_ctc_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(CtcBatch)]),
     "sctc_ctc_loss_batch": (ctypes.c_int, [ctypes.POINTER(CtcBatch), vp, vp, vp, vp, vp,
                                            ctypes.c_size_t, vp]),
@@ -76,6 +75,7 @@ PROTOTYPES = {
     "sctc_brnn_cost_and_grad_async": (ctypes.c_int, [vp, ctypes.POINTER(Minibatch),
                                                      ctypes.c_int32, vp, vp, vp]),
     "sctc_brnn_check": (ctypes.c_int, [vp, vp]),
+    "sctc_brnn_recurrent_path": (ctypes.c_int, [vp, c_i32p, c_i32p, c_i32p]),
     "sctc_brnn_grad_event": (vp, [vp, ctypes.c_int32]),
     "sctc_stream_wait_event": (ctypes.c_int, [vp, vp]),
     "sctc_brnn_forward": (ctypes.c_int, [vp, ctypes.POINTER(Minibatch), vp, vp]),
@@ -97,7 +97,7 @@ PROTOTYPES = {
     "sctc_nesterov_step": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_float,
                                           ctypes.c_float, ctypes.c_float, ctypes.c_float, vp,
                                           vp]),
-    "sctc_sumsq_reg": (ctypes.c_int, [vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_int64,
+    "sctc_sumsq_reg": (ctypes.c_int, [vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int64,
                                       c_i64p, ctypes.c_int32, vp, vp, ctypes.c_size_t, vp]),
     "sctc_nesterov_step_reg": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_float,
                                               ctypes.c_float, ctypes.c_float, ctypes.c_float,
@@ -113,6 +113,23 @@ _lib = None
 
 class SctcError(RuntimeError):
     pass
+
+
+def _ranks_share_a_device():
+    """True when torch.distributed.run put more local ranks on this node than there are visible
+    GPUs (e.g. a 2-rank rehearsal on a 1-GPU box): the persistent recurrent launches of the ranks
+    must then take turns (sctc_set_shared_device, include/sctc.h)."""
+    try:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    except ValueError:
+        return False
+    if local_world <= 1:
+        return False
+    try:
+        import torch
+        return local_world > max(1, torch.cuda.device_count())
+    except Exception:
+        return False
 
 
 def lib():
@@ -134,9 +151,11 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if L.sctc_abi_version() != 2:
+        if L.sctc_abi_version() != 3:
             raise ImportError("libsctc_hip.so ABI version mismatch")
         _lib = L
+        if "SCTC_SHARED_DEVICE" not in os.environ and _ranks_share_a_device():
+            L.sctc_set_shared_device(1)
     return _lib
 
 

@@ -105,7 +105,10 @@ struct sctc_brnn {
     float phase_ms[SCTC_N_PHASES];
     int rec_sync_mode = 0;
     int rec_poll_delay = -1;   // env SCTC_REC_POLL_DELAY (s_sleep units before a step's first poll; default by layer size)
-    int rec_variant = 0;   // env SCTC_REC_VARIANT: 1 forces the one-workgroup-per-CU recurrent kernel
+    int rec_variant = 0;   // env SCTC_REC_VARIANT: 1 forces the one-workgroup-per-CU recurrent kernel, 3 the per-step fallback
+    int rec_force_fallback = 0;   // set while a timed-out step is retried on the per-step fallback
+    int rec_path[2] = {0, 0};     // REC_PATH_* of the last forward / BPTT recurrence
+    int rec_retries = 0;          // steps of this handle that were re-run after SCTC_ERR_TIMEOUT
     // host staging of the CTC descriptors (must outlive the async uploads)
     void* ctc_stage = nullptr;
     std::vector<int32_t> ctc_U, ctc_labels;
@@ -440,7 +443,7 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
     // brnnet.py:136 hActs[0] <- data, here also the re-ordering into the packed layout
     const bool h16 = h->cfg.operand_dtype == SCTC_F16;
     if (h16) {
-        SCTC_TRY(launch_gather_rows16(h->X0, h->act16f[0], h->cfg.train ? h->act16b[0] : h->act16f[0], LD(h->Dp),
+        SCTC_TRY(launch_gather_rows16(h->X0, h->act16f[0], h->cfg.train ? h->act16b[0] : nullptr, LD(h->Dp),
                                       mb->feats_dev, h->D, h->d_src_row, N, h->D, s));
         // parameters change between calls: their 16-bit copies are refreshed per call (35 M elements)
         SCTC_TRY(launch_cvt16(h->params, h->W16f, nullptr, round_up(h->param_elems, 4), s));
@@ -507,12 +510,12 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
             r.n_xrows = (int)h->n_xrows;
             r.counters = h->counters;
             r.sync_mode = h->rec_sync_mode;
-            r.variant = h->rec_variant;
+            r.variant = h->rec_force_fallback ? 3 : h->rec_variant;
             r.poll_delay = h->rec_poll_delay;
             r.debug = h->rec_debug_on ? h->rec_debug : nullptr;
             r.prec16 = h->cfg.operand_dtype == SCTC_F16;
             r.T_host = h->Ts.data();
-            SCTC_TRY(launch_recurrent(r, s));
+            SCTC_TRY(launch_recurrent(r, s, &h->rec_path[0]));
             pt.begin(SCTC_PHASE_OTHER);
             // hActs[i] = hActsFor + hActsBack, brnnet.py:153
             if (h16) {
@@ -537,10 +540,36 @@ static int check_recurrent_error(sctc_brnn* h, hipStream_t s)
     unsigned e = 0;
     SCTC_HIP_TRY(hipMemcpyAsync(&e, h->counters + 2, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     SCTC_HIP_TRY(hipStreamSynchronize(s));
-    if (e != 0)
-        return set_error(SCTC_ERR_TIMEOUT, "recurrent kernel: grid barrier timed out (are all %d "
-                         "workgroups co-resident?)", 2 * (h->Hp / 16));
+    if (e != 0) {
+        // whoever else holds compute units of this device will still be there on the next launch:
+        // from now on every persistent launch of this process takes the inter-process lease
+        recurrent_set_shared_device_mode(1);
+        return set_error(SCTC_ERR_TIMEOUT, "recurrent kernel: a persistent launch gave up waiting for "
+                         "its peers (the %d workgroups of a pass were not co-resident: device shared "
+                         "with another process or CU-masked); shared-device mode is now on",
+                         2 * (h->Hp / 16));
+    }
     return SCTC_OK;
+}
+
+// A timed-out step is re-run: first under the inter-process lease (check_recurrent_error has just
+// switched shared-device mode on), then on the per-step fallback, which cannot time out.  Not
+// possible when the step accumulates into the gradients (the failed attempt has already added
+// garbage): that error goes to the caller.
+template <typename Step>
+static int with_retry(sctc_brnn* h, bool retry_ok, Step step)
+{
+    int rc = step();
+    for (int attempt = 0; rc == SCTC_ERR_TIMEOUT && retry_ok && attempt < 2; ++attempt) {
+        if (getenv("SCTC_VERBOSE"))
+            fprintf(stderr, "sctc: %s -- retrying the step %s\n", err_buf(),
+                    attempt == 0 ? "under the device lease" : "on the per-step fallback");
+        ++h->rec_retries;
+        h->rec_force_fallback = attempt == 1;
+        rc = step();
+        h->rec_force_fallback = 0;
+    }
+    return rc;
 }
 
 // ------------------------------------------------------------------ CTC + backward
@@ -712,12 +741,12 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             r.n_xrows = (int)h->n_xrows;
             r.counters = h->counters;
             r.sync_mode = h->rec_sync_mode;
-            r.variant = h->rec_variant;
+            r.variant = h->rec_force_fallback ? 3 : h->rec_variant;
             r.poll_delay = h->rec_poll_delay;
             r.debug = h->rec_debug_on ? h->rec_debug + REC_DEBUG_WORDS : nullptr;
             r.prec16 = h->cfg.operand_dtype == SCTC_F16;
             r.T_host = h->Ts.data();
-            SCTC_TRY(launch_recurrent(r, s));
+            SCTC_TRY(launch_recurrent(r, s, &h->rec_path[1]));
             pt.begin(SCTC_PHASE_BWD_GEMM);
             if (h16) {   // A operands of the recurrent weight gradient
                 SCTC_TRY(launch_cvt16(h->dF, nullptr, h->dF16b, N * LD(h->Hp), s));
@@ -935,9 +964,9 @@ int sctc_brnn_check(sctc_brnn_t h, void* stream)
     return check_recurrent_error(h, (hipStream_t)stream);
 }
 
-int sctc_brnn_cost_and_grad(sctc_brnn_t h, const sctc_minibatch* mb, int32_t flags,
-                            double* cost_host, int32_t* skip_host, double* regcost_host,
-                            void* stream)
+static int cost_and_grad_once(sctc_brnn_t h, const sctc_minibatch* mb, int32_t flags,
+                              double* cost_host, int32_t* skip_host, double* regcost_host,
+                              void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     bool all_skipped = false;
@@ -973,9 +1002,18 @@ int sctc_brnn_cost_and_grad(sctc_brnn_t h, const sctc_minibatch* mb, int32_t fla
     return SCTC_OK;
 }
 
-int sctc_brnn_forward(sctc_brnn_t h, const sctc_minibatch* mb, float* probs_dev, void* stream)
+int sctc_brnn_cost_and_grad(sctc_brnn_t h, const sctc_minibatch* mb, int32_t flags,
+                            double* cost_host, int32_t* skip_host, double* regcost_host,
+                            void* stream)
 {
-    SCTC_CHECK_ARG(h && probs_dev, "brnn_forward: null argument");
+    SCTC_CHECK_ARG(h, "brnn_cost_and_grad: null handle");
+    return with_retry(h, !(flags & SCTC_FLAG_ACCUMULATE), [&]() {
+        return cost_and_grad_once(h, mb, flags, cost_host, skip_host, regcost_host, stream);
+    });
+}
+
+static int forward_once(sctc_brnn_t h, const sctc_minibatch* mb, float* probs_dev, void* stream)
+{
     hipStream_t s = (hipStream_t)stream;
     PhaseTimer pt{h, s};
     if (h->profiling) memset(h->phase_ms, 0, sizeof(h->phase_ms));
@@ -985,6 +1023,29 @@ int sctc_brnn_forward(sctc_brnn_t h, const sctc_minibatch* mb, float* probs_dev,
     SCTC_TRY(launch_scatter_rows(probs_dev, h->A, h->probs, LD(h->Ap), h->d_src_row, h->N, h->A, s));
     pt.end();
     return check_recurrent_error(h, s);
+}
+
+int sctc_brnn_forward(sctc_brnn_t h, const sctc_minibatch* mb, float* probs_dev, void* stream)
+{
+    SCTC_CHECK_ARG(h && probs_dev, "brnn_forward: null argument");
+    return with_retry(h, true, [&]() { return forward_once(h, mb, probs_dev, stream); });
+}
+
+int sctc_set_shared_device(int32_t on)
+{
+    recurrent_set_shared_device_mode(on);
+    return SCTC_OK;
+}
+
+int sctc_shared_device(void) { return recurrent_shared_device_mode(); }
+
+int sctc_brnn_recurrent_path(sctc_brnn_t h, int32_t* forward_path, int32_t* bptt_path, int32_t* retries)
+{
+    SCTC_CHECK_ARG(h, "brnn_recurrent_path: null handle");
+    if (forward_path) *forward_path = h->rec_path[0];
+    if (bptt_path) *bptt_path = h->rec_path[1];
+    if (retries) *retries = h->rec_retries;
+    return SCTC_OK;
 }
 
 /* diagnostics: s_memtime stamps of the recurrent kernel (SCTC_REC_DEBUG=1), [2 passes][2 wgs][16 steps][8] */

@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void gather_rows16_kernel(float* __restrict__ 
     for (int c = lane; c < ldd; c += 64) {
         const float v = c < cols ? s[c] : 0.f;
         dst[r * ldd + c] = v;
-        d16a[r * ldd + c] = to_f16(v);
-        d16b[r * ldd + c] = to_bf16(v);
+        if (d16a) d16a[r * ldd + c] = to_f16(v);      // either shadow may be absent (forward-only
+        if (d16b) d16b[r * ldd + c] = to_bf16(v);     // models have no bfloat16 shadows)
     }
 }
 
@@ -185,21 +185,30 @@ __global__ __launch_bounds__(256) void nesterov_kernel(float* __restrict__ w, fl
     }
 }
 
-// minibatch / data-parallel form: effective gradient e = grad_scale*g + reg*w (the L2 term once);
-// the bias ranges of the flat buffer carry no L2 term
+// minibatch / data-parallel form: effective gradient e = grad_scale*g + reg*(w + mom*v) -- the L2
+// term once, evaluated where the reference evaluates it: at the Nesterov look-ahead point
+// (sgd.py:91-93 moves the weights to w + mom*v before costAndGrad, brnnet.py:197-198 adds reg*W
+// there; `w` here is the weight after the look-ahead has been undone, `v` the velocity before this
+// step's update).  The bias ranges of the flat buffer carry no L2 term.
+static constexpr int MAX_NOREG_RANGES = 128;
 struct NoRegRanges {
-    int n;
-    int64_t beg[32], end[32];
+    int n;                                  // ranges; edge[2k], edge[2k+1] = [beg, end) ascending, disjoint
+    int64_t edge[2 * MAX_NOREG_RANGES];
 };
 __device__ __forceinline__ float reg_at(const NoRegRanges& r, int64_t i, float reg)
 {
-    bool in = false;
-    for (int k = 0; k < r.n; ++k) in = in || (i >= r.beg[k] && i < r.end[k]);
-    return in ? 0.f : reg;
+    // upper bound over the sorted edges: an odd count of edges <= i means i lies inside a range
+    int lo = 0, hi = 2 * r.n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (r.edge[mid] <= i) lo = mid + 1; else hi = mid;
+    }
+    return (lo & 1) ? 0.f : reg;
 }
 
 __global__ __launch_bounds__(256) void sumsq_reg_partial_kernel(const float* __restrict__ g,
                                                                 const float* __restrict__ w,
+                                                                const float* __restrict__ vel, float mom,
                                                                 float grad_scale, float reg,
                                                                 NoRegRanges nr, int64_t n,
                                                                 double* __restrict__ partial)
@@ -207,7 +216,8 @@ __global__ __launch_bounds__(256) void sumsq_reg_partial_kernel(const float* __r
     __shared__ double sh[256];
     double s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const double v = (double)(grad_scale * g[i] + reg_at(nr, i, reg) * w[i]);
+        const float wl = vel ? w[i] + mom * vel[i] : w[i];
+        const double v = (double)(grad_scale * g[i] + reg_at(nr, i, reg) * wl);
         s += v * v;
     }
     sh[threadIdx.x] = s;
@@ -232,8 +242,9 @@ __global__ __launch_bounds__(256) void nesterov_reg_kernel(float* __restrict__ w
         if (gnorm > (double)max_gnorm) alph = (float)((double)alpha * ((double)max_gnorm / gnorm));
     }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float e = grad_scale * g[i] + reg_at(nr, i, reg) * w[i];
-        const float nv = mom * v[i] - alph * e;
+        const float vo = v[i];
+        const float e = grad_scale * g[i] + reg_at(nr, i, reg) * (w[i] + mom * vo);
+        const float nv = mom * vo - alph * e;
         v[i] = nv;
         w[i] += nv;
     }
@@ -377,13 +388,18 @@ int sctc_nesterov_step(float* w_dev, float* v_dev, const float* g_dev, int64_t n
 
 static int make_ranges(const int64_t* host, int32_t n, NoRegRanges* out)
 {
-    SCTC_CHECK_ARG(n >= 0 && n <= 32 && (n == 0 || host), "noreg ranges: 0..32 [beg,end) pairs");
+    SCTC_CHECK_ARG(n >= 0 && n <= MAX_NOREG_RANGES && (n == 0 || host),
+                   "noreg ranges: 0..%d [beg,end) pairs (got %d)", MAX_NOREG_RANGES, n);
     out->n = n;
-    for (int k = 0; k < n; ++k) { out->beg[k] = host[2 * k]; out->end[k] = host[2 * k + 1]; }
+    for (int k = 0; k < 2 * n; ++k) {
+        out->edge[k] = host[k];
+        SCTC_CHECK_ARG(k == 0 || host[k] >= host[k - 1], "noreg ranges must be ascending and disjoint");
+    }
     return SCTC_OK;
 }
 
-int sctc_sumsq_reg(const float* g_dev, const float* w_dev, float grad_scale, float reg, int64_t n,
+int sctc_sumsq_reg(const float* g_dev, const float* w_dev, const float* v_dev, float mom,
+                   float grad_scale, float reg, int64_t n,
                    const int64_t* noreg_ranges_host, int32_t n_ranges, double* out_dev,
                    void* workspace_dev, size_t workspace_bytes, void* stream)
 {
@@ -395,7 +411,7 @@ int sctc_sumsq_reg(const float* g_dev, const float* w_dev, float grad_scale, flo
                          sumsq_ws_bytes());
     const int blocks = (int)std::min<int64_t>(SS_BLOCKS, std::max<int64_t>(1, (n + 255) / 256));
     hipLaunchKernelGGL(sumsq_reg_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       g_dev, w_dev, grad_scale, reg, nr, n, (double*)workspace_dev);
+                       g_dev, w_dev, v_dev, mom, grad_scale, reg, nr, n, (double*)workspace_dev);
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
                        (const double*)workspace_dev, blocks, out_dev);
     SCTC_HIP_TRY(hipGetLastError());

@@ -38,7 +38,8 @@ struct RecArgs {
                             // 1: write-through (sc1) exchange stores, no fence
     int32_t poll_delay;     // s_sleep units (64 cycles) before the first poll of a step; < 0: pick by layer size
     int32_t variant;        // 0: pick automatically; 1: force the one-workgroup-per-CU kernel;
-                            // 2: two-chain kernel with the linear (not XCD-grouped) block map
+                            // 2: two-chain kernel with the linear (not XCD-grouped) block map;
+                            // 3: force the non-persistent per-step fallback
     unsigned* debug;        // nullable: s_memtime stamps [2 wgs][16 steps][8] for steps 64..79
     int32_t b_off;          // rank of this launch's first utterance in the packed minibatch (minibatches of
                             // more than 128 utterances run as several launches; T_b already points at it)
@@ -61,6 +62,15 @@ static constexpr int REC_COUNTER_WORDS = 32 + 4 * 128 * REC_FLAG_STRIDE;   // er
 static inline int64_t recurrent_xrows_bound(int64_t rows, int64_t tmax) { return rows + 3 * tmax; }
 size_t recurrent_xbuf_floats(int Hp, int64_t max_xrows);
 int recurrent_supported(int Hp, int B, char* why, int why_len);
-int launch_recurrent(const RecArgs& a, hipStream_t stream);
+// which path a launch_recurrent call took (`path` out-parameter, nullable)
+static constexpr int REC_PATH_NONE = 0;
+static constexpr int REC_PATH_PERSISTENT = 1;          // one whole-device persistent launch per pass
+static constexpr int REC_PATH_PERSISTENT_LEASED = 2;   // the same under the inter-process device lease
+static constexpr int REC_PATH_FALLBACK = 3;            // one launch per time step (no spinning)
+int launch_recurrent(const RecArgs& a, hipStream_t stream, int* path = nullptr);
+// shared-device mode: persistent launches take an inter-process lease (flock on a per-device file)
+// and run synchronously.  Initial value: SCTC_SHARED_DEVICE in the environment.
+int recurrent_shared_device_mode();
+void recurrent_set_shared_device_mode(int on);
 
 }  // namespace sctc

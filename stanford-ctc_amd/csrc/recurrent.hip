@@ -26,14 +26,23 @@
 // same-XCD readers of a line share one fabric fetch.
 //   sync_mode 0: plain payload stores + agent-scope release fence before the flag;
 //   sync_mode 1: write-through (sc1) payload stores, no fence.
-// Every spin is bounded (3 s) and raises an error word the host turns into
+// Every spin is bounded (0.5 s) and raises an error word the host turns into
 // SCTC_ERR_TIMEOUT; flags are zeroed by a memset node before each launch.
 //
 // The K index inside a 16-chunk is permuted (k = 16c + 4*(lane>>4) + q for MFMA q)
 // identically for W and x, so both operands are 16-byte vector loads.
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
+#include <utility>
+#include <vector>
+
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <sys/file.h>
+#include <unistd.h>
 
 #include "common.h"
 #include "recurrent.h"
@@ -46,7 +55,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-static constexpr unsigned long long SPIN_TIMEOUT_TICKS = 300000000ull;  // 3 s of the 100 MHz clock
+// A wait only ever expires when some workgroup of the grid is not running (device shared with
+// another persistent launch, CU masking): 0.5 s of the 100 MHz clock is 5 orders of magnitude above
+// a step and still fails a caller quickly.  The host then retries (device lease, per-step fallback).
+static constexpr unsigned long long SPIN_TIMEOUT_TICKS = 50000000ull;
 
 // s_sleep units (64 cycles) a consumer waits before its FIRST poll of a step (RecArgs.poll_delay).
 // A poll is a fabric round trip (~1 us); one issued the moment the own results are published is
@@ -1073,6 +1085,91 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_mh_kernel(RecArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Non-persistent fallback: ONE launch per time step, both directions -- the structure of the
+// reference itself (brnnet.py:148-152: mvdot_col_slice + minmax per step; :215-224 BPTT), used
+// whenever a whole-device persistent grid cannot be guaranteed co-resident: the device is shared
+// with another process and the lease cannot be had, the grid is larger than the device (layers
+// beyond 2048 units, CU masking), or a persistent launch has timed out and the step is retried.
+// Workgroup (chunk, direction, utterance tile) computes 16 units x 16 utterances of step j:
+// 4 waves = 4 K quarters on v_mfma_f32_16x16x4_f32, weights streamed from L2 / the Infinity
+// Cache (13.3 MB per direction at H = 1824), the previous state read straight from the rows of
+// the output matrix that the launch of step j-1 wrote (stream order is the step barrier: no
+// exchange buffer, no flags, no spinning).  ~4x slower than the persistent kernels, always safe.
+__global__ __launch_bounds__(256) void brnn_recurrent_step_kernel(RecArgs p, int j)
+{
+    __shared__ float4 red[3 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x, g = blockIdx.y, tile = blockIdx.z;
+    // utterances are sorted by length: a tile is finished once its first utterance is
+    const int Ttile = tile * 16 < p.B ? p.T_b[tile * 16] : 0;
+    if (j >= Ttile) return;
+    const int nch = p.Hp >> 4;
+    const int row0 = wg * 16;
+    const int uj = lane & 15, kq = lane >> 4;
+    const int base = nch >> 2, rem = nch & 3;
+    const int cnt = base + (wave < rem ? 1 : 0);
+    const int c_beg = wave * base + min(wave, rem);
+    const bool desc = p.descending[g] != 0;
+    const float* W = p.W[g];
+    const float* pre = p.pre[g];
+    const float* act = p.act[g];
+    float* out = p.out[g];
+    const int64_t ld = p.ld;
+    const float hi = p.max_act > 0.f ? p.max_act : INFINITY;
+    const int ub = tile * 16 + uj;
+    const int uT = ub < p.B ? p.T_b[ub] : 0;
+    const bool active = j < uT;
+    const int t = desc ? uT - 1 - j : j;
+    const int tp = desc ? t + 1 : t - 1;
+    const int64_t orow = active ? (int64_t)p.rowbase[t] + p.b_off + ub : 0;
+    // finished / empty slots read row 0 (valid memory, result discarded)
+    const int64_t prow = (active && j > 0) ? (int64_t)p.rowbase[tp] + p.b_off + ub : 0;
+    float4 pre4 = make_float4(0.f, 0.f, 0.f, 0.f), act4 = pre4;
+    if (wave == 0 && active) {
+        pre4 = *reinterpret_cast<const float4*>(pre + orow * ld + row0 + 4 * kq);
+        if (act) act4 = *reinterpret_cast<const float4*>(act + orow * ld + row0 + 4 * kq);
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = {0.f, 0.f, 0.f, 0.f};
+    if (j > 0) {
+        const float* xr = out + prow * ld + 4 * kq;
+        for (int u = 0; u < cnt; ++u) {
+            const int c = c_beg + u;
+            float4 a;
+            if (!p.transpose) {
+                a = *reinterpret_cast<const float4*>(W + (int64_t)(row0 + uj) * p.ldw + 16 * c + 4 * kq);
+            } else {
+                const float* col = W + (int64_t)(16 * c + 4 * kq) * p.ldw + row0 + uj;
+                a.x = col[0];
+                a.y = col[p.ldw];
+                a.z = col[2 * p.ldw];
+                a.w = col[3 * p.ldw];
+            }
+            const float4 x = *reinterpret_cast<const float4*>(xr + 16 * c);
+            SCTC_MFMA4(acc, a, x)
+        }
+        if (wave != 0) {
+            const f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            red[(wave - 1) * 64 + lane] = make_float4(s[0], s[1], s[2], s[3]);
+        }
+        __syncthreads();
+    }
+    if (wave == 0 && active) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j > 0) {
+            const float4 r1 = red[lane], r2 = red[64 + lane], r3 = red[128 + lane];
+            const f32x4 q = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            s = make_float4((q[0] + r1.x) + (r2.x + r3.x), (q[1] + r1.y) + (r2.y + r3.y),
+                            (q[2] + r1.z) + (r2.z + r3.z), (q[3] + r1.w) + (r2.w + r3.w));
+        }
+        const float4 o = step_result(pre4, s, act4, act != nullptr, hi);
+        *reinterpret_cast<float4*>(out + orow * ld + row0 + 4 * kq) = o;
+    }
+}
+
 size_t recurrent_xbuf_floats(int Hp, int64_t max_xrows)
 {
     return (size_t)2 * (size_t)max_xrows * Hp;  // one chunk-major state copy per direction
@@ -1081,13 +1178,8 @@ size_t recurrent_xbuf_floats(int Hp, int64_t max_xrows)
 int recurrent_supported(int Hp, int B, char* why, int why_len)
 {
     if (Hp % 32 != 0) { snprintf(why, why_len, "layer size %d not padded to 32", Hp); return 0; }
-    if (2 * (Hp / 16) > 256) {
-        snprintf(why, why_len, "layer size %d needs %d co-resident workgroups (> 256 CUs)", Hp,
-                 2 * (Hp / 16));
-        return 0;
-    }
     (void)B;   // any minibatch size: more than 128 utterances run as several launches
-    return 1;
+    return 1;  // any layer size: grids beyond the device run on the per-step fallback
 }
 
 template <int NTW>
@@ -1102,56 +1194,228 @@ static RecKernel pick_kernel(int nch_half)
     }
 }
 
+// ------------------------------------------------------------------ co-residency guards
+//
 // Persistent kernels spin on other workgroups: every workgroup of the grid must be resident at
-// once.  The dynamic-LDS attribute is set once per kernel (not per step) and the grid is checked
-// against the occupancy the runtime reports, so that a grid that cannot be co-resident (another
-// process on the device, CU masking, a profiler holding LDS) fails fast or falls back instead of
-// spinning into the 3 s timeout.
-static int prepare_kernel(RecKernel k, size_t smem, int grid, int cus, bool* fits)
+// once.  Three things can break that, each with its own guard:
+//  (1) the grid does not fit the device at all (occupancy x CUs < grid): checked per (device,
+//      kernel) before the launch -> the per-step fallback runs instead;
+//  (2) ANOTHER PROCESS launches a persistent grid on the same device at the same time (two ranks
+//      sharing one GPU): both get part of the CUs and spin forever.  "Shared-device mode" takes an
+//      inter-process lease -- flock() on a per-device file in /dev/shm -- around every persistent
+//      launch: stream drained, lock, launch, wait, unlock.  It is on when SCTC_SHARED_DEVICE=1
+//      (the Python mirror sets it when the local ranks outnumber the visible devices) and turns
+//      itself on for the rest of the process the first time a launch times out; the normal
+//      one-rank-per-GPU path pays nothing;
+//  (3) another STREAM of this process does the same (one-utterance-per-stream): the in-process
+//      gate below admits a persistent launch only while the CUs of all persistent launches in
+//      flight on other streams, plus its own, fit the device; otherwise it first waits (on the
+//      host) for the oldest of them.
+// What still gets through (CU masks the runtime does not report, a foreign persistent kernel of
+// some other library) ends in the bounded spin -> SCTC_ERR_TIMEOUT -> the engine retries the step
+// on the fallback.
+
+static std::atomic<int> g_shared_mode{-1};   // -1: not yet read from the environment
+
+int recurrent_shared_device_mode()
+{
+    int m = g_shared_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("SCTC_SHARED_DEVICE");
+        m = (e && atoi(e) != 0) ? 1 : 0;
+        g_shared_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
+void recurrent_set_shared_device_mode(int on) { g_shared_mode.store(on ? 1 : 0, std::memory_order_relaxed); }
+
+namespace {
+
+struct DeviceLease {      // inter-process: one lock file per physical device
+    std::mutex mu;                       // serialises the threads of this process (flock is per open file)
+    std::map<int, int> fds;
+    int fd_for(int dev)
+    {
+        auto it = fds.find(dev);
+        if (it != fds.end()) return it->second;
+        char bus[64] = "unknown";
+        (void)hipDeviceGetPCIBusId(bus, sizeof(bus), dev);
+        for (char* c = bus; *c; ++c)
+            if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+        char path[160];
+        int fd = -1;
+        const char* dirs[2] = {"/dev/shm", "/tmp"};
+        for (int k = 0; k < 2 && fd < 0; ++k) {
+            snprintf(path, sizeof(path), "%s/sctc_gpu_%s.lock", dirs[k], bus);
+            fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+            if (fd >= 0) (void)fchmod(fd, 0666);
+        }
+        fds[dev] = fd;
+        return fd;
+    }
+};
+DeviceLease g_lease;
+
+struct LeaseGuard {
+    int fd = -1;
+    bool locked = false;
+    explicit LeaseGuard(int dev)
+    {
+        g_lease.mu.lock();
+        fd = g_lease.fd_for(dev);
+        if (fd >= 0) {
+            int rc;
+            do { rc = flock(fd, LOCK_EX); } while (rc != 0 && errno == EINTR);
+            locked = rc == 0;
+        }
+    }
+    ~LeaseGuard()
+    {
+        if (locked) (void)flock(fd, LOCK_UN);
+        g_lease.mu.unlock();
+    }
+};
+
+struct PersistentGate {   // in-process: persistent launches in flight, per device
+    struct Entry { hipEvent_t ev; hipStream_t stream; int cus; };
+    std::mutex mu;
+    std::map<int, std::vector<Entry>> inflight;
+    std::vector<hipEvent_t> pool;
+
+    // blocks (on the host) until `cus` more compute units' worth of persistent workgroups fit
+    // next to what other streams have in flight
+    int admit(int dev, hipStream_t stream, int cus, int device_cus)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        std::vector<Entry>& v = inflight[dev];
+        for (;;) {
+            int other = 0;
+            for (size_t i = 0; i < v.size();) {
+                const hipError_t q = hipEventQuery(v[i].ev);
+                if (q == hipSuccess) {
+                    pool.push_back(v[i].ev);
+                    v.erase(v.begin() + i);
+                    continue;
+                }
+                if (q != hipErrorNotReady) (void)hipGetLastError();
+                if (v[i].stream != stream) other += v[i].cus;   // same stream: serialised anyway
+                ++i;
+            }
+            if (other == 0 || other + cus <= device_cus) return SCTC_OK;
+            for (size_t i = 0; i < v.size(); ++i)
+                if (v[i].stream != stream) {
+                    SCTC_HIP_TRY(hipEventSynchronize(v[i].ev));
+                    break;
+                }
+        }
+    }
+    int launched(int dev, hipStream_t stream, int cus)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        hipEvent_t ev;
+        if (!pool.empty()) { ev = pool.back(); pool.pop_back(); }
+        else SCTC_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        SCTC_HIP_TRY(hipEventRecord(ev, stream));
+        inflight[dev].push_back(Entry{ev, stream, cus});
+        return SCTC_OK;
+    }
+};
+PersistentGate g_gate;
+
+}  // namespace
+
+// The dynamic-LDS attribute is set once per (device, kernel) and the grid is checked against the
+// blocks per CU the kernel can have: its LDS share (these kernels are LDS-limited by construction,
+// their __launch_bounds__ guarantee the registers for 1 or 2 blocks per CU; the runtime's
+// occupancy query under-reports kernels that use most of the 160 KiB -- it says 1 for the
+// two-chain kernel at 2 x 79 KiB, which does run two per CU -- so it is only the second opinion).
+static int prepare_kernel(RecKernel k, size_t smem, int max_per_cu, int dev, int* blocks_per_cu)
 {
     struct Info { size_t smem_set = 0; size_t occ_smem = (size_t)-1; int occ = 0; };
     static std::mutex mu;
-    static std::map<const void*, Info> table;
+    static std::map<std::pair<int, const void*>, Info> table;
     std::lock_guard<std::mutex> lock(mu);
-    Info& in = table[reinterpret_cast<const void*>(k)];
+    Info& in = table[std::make_pair(dev, reinterpret_cast<const void*>(k))];
     if (in.smem_set < smem) {
         SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         in.smem_set = smem;
     }
     if (in.occ_smem != smem) {
-        int n = 0, dev = 0, lds = 0;
+        int n = 0, lds = 0;
         SCTC_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), 256, smem));
-        // The query under-reports kernels that use most of the 160 KiB LDS (measured: 1 block per CU
-        // for the two-chain kernel at 2 x 79 KiB, which does run two per CU), so the LDS budget
-        // itself is the second opinion: these kernels are LDS-limited by construction (their
-        // __launch_bounds__ guarantee the registers for 1 or 2 blocks per CU).
-        SCTC_HIP_TRY(hipGetDevice(&dev));
         SCTC_HIP_TRY(hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev));
-        const int by_lds = smem ? (int)std::min<size_t>(2, (size_t)lds / smem) : 2;
-        in.occ = std::max(n, by_lds);
+        const int by_lds = smem ? (int)std::min<size_t>((size_t)max_per_cu, (size_t)lds / smem) : max_per_cu;
+        in.occ = std::max(std::min(n, max_per_cu), by_lds);
         in.occ_smem = smem;
         if (getenv("SCTC_VERBOSE"))
-            fprintf(stderr, "sctc: recurrent kernel %p: %zu B LDS, occupancy query %d, LDS model %d blocks/CU\n",
-                    reinterpret_cast<const void*>(k), smem, n, by_lds);
+            fprintf(stderr, "sctc: recurrent kernel %p on device %d: %zu B LDS, occupancy query %d, LDS model %d blocks/CU\n",
+                    reinterpret_cast<const void*>(k), dev, smem, n, by_lds);
     }
-    *fits = (int64_t)in.occ * cus >= grid;
+    *blocks_per_cu = in.occ;
     return SCTC_OK;
 }
 
-static int not_resident(const char* which, int grid, int cus)
+static int launch_fallback(const RecArgs& a, hipStream_t stream)
 {
-    return set_error(SCTC_ERR_STATE, "recurrent kernel (%s): %d workgroups cannot be co-resident on "
-                     "%d compute units (occupancy query) -- is the device shared or CU-masked?",
-                     which, grid, cus);
+    const int nch = a.Hp / 16, ntiles = (a.B + 15) / 16;
+    for (int j = 0; j < a.Tmax; ++j)
+        hipLaunchKernelGGL(brnn_recurrent_step_kernel, dim3(nch, 2, ntiles), dim3(256), 0, stream, a, j);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
 }
 
-static int launch_recurrent_one(const RecArgs& a, int cus, hipStream_t stream)
+struct LaunchCtx {
+    int dev, cus;
+    hipStream_t stream;
+    int* path;      // out: REC_PATH_* of the last launch
+};
+
+// launches a persistent grid if it can be co-resident (returns 1), else leaves it to the caller (0)
+static int launch_persistent(RecKernel k, int grid, size_t smem, int max_per_cu, size_t sentinel_bytes,
+                             const RecArgs& a, const LaunchCtx& cx, bool* done)
+{
+    *done = false;
+    int per_cu = 0;
+    SCTC_TRY(prepare_kernel(k, smem, max_per_cu, cx.dev, &per_cu));
+    if (per_cu < 1 || (int64_t)per_cu * cx.cus < grid) return SCTC_OK;
+    const int need_cus = (grid + per_cu - 1) / per_cu;
+    if (sentinel_bytes)   // sentinel-fill the exchange rows (both directions)
+        SCTC_HIP_TRY(hipMemsetAsync(a.xbuf, 0xFF, sentinel_bytes, cx.stream));
+    if (recurrent_shared_device_mode()) {
+        // the lease is held exactly while the grid runs: nothing of ours queued in front of it,
+        // nobody else's persistent grid next to it
+        SCTC_HIP_TRY(hipStreamSynchronize(cx.stream));
+        LeaseGuard lease(cx.dev);
+        if (!lease.locked) return SCTC_OK;            // no lock file to be had: per-step fallback
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, cx.stream, a);
+        SCTC_HIP_TRY(hipGetLastError());
+        SCTC_HIP_TRY(hipStreamSynchronize(cx.stream));
+        *done = true;
+        if (cx.path) *cx.path = REC_PATH_PERSISTENT_LEASED;
+        return SCTC_OK;
+    }
+    SCTC_TRY(g_gate.admit(cx.dev, cx.stream, need_cus, cx.cus));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, cx.stream, a);
+    SCTC_HIP_TRY(hipGetLastError());
+    SCTC_TRY(g_gate.launched(cx.dev, cx.stream, need_cus));
+    *done = true;
+    if (cx.path) *cx.path = REC_PATH_PERSISTENT;
+    return SCTC_OK;
+}
+
+static int launch_recurrent_one(const RecArgs& a, const LaunchCtx& cx)
 {
     const int nwg = a.Hp / 16;
     const int ntiles = (a.B + 15) / 16;
-    bool fits = false;
+    hipStream_t stream = cx.stream;
+    bool done = false;
     SCTC_HIP_TRY(hipMemsetAsync(a.counters, 0, REC_COUNTER_WORDS * sizeof(unsigned), stream));
+    if (a.variant == 3 || 2 * nwg > cx.cus) {
+        if (cx.path) *cx.path = REC_PATH_FALLBACK;
+        return launch_fallback(a, stream);
+    }
     // measured at H=1824: 2.5 us per step for one utterance + ~1.2 us per further one (VALU FMAs),
     // against 7.4 us for the flag/MFMA kernel: worth it up to 5 utterances
     if (a.B <= 5 && a.variant != 1) {
@@ -1166,13 +1430,8 @@ static int launch_recurrent_one(const RecArgs& a, int cus, hipStream_t stream)
         }
         if (sk) {
             const size_t smem = sizeof(float) * 2 * (s4 ? 4 : 8) * a.Hp;
-            SCTC_TRY(prepare_kernel(sk, smem, 2 * nwg, cus, &fits));
-            if (!fits) return not_resident("1..5 utterances", 2 * nwg, cus);
-            // sentinel-fill the exchange rows (both directions)
-            SCTC_HIP_TRY(hipMemsetAsync(a.xbuf, 0xFF, (size_t)2 * a.n_xrows * a.Hp * sizeof(float), stream));
-            hipLaunchKernelGGL(sk, dim3(2 * nwg), dim3(256), smem, stream, a);
-            SCTC_HIP_TRY(hipGetLastError());
-            return SCTC_OK;
+            SCTC_TRY(launch_persistent(sk, 2 * nwg, smem, 1, (size_t)2 * a.n_xrows * a.Hp * sizeof(float), a, cx, &done));
+            if (done) return SCTC_OK;
         }
     }
     if (a.prec16 && a.B > 5 && a.B <= 16 && a.variant != 1) {
@@ -1189,12 +1448,8 @@ static int launch_recurrent_one(const RecArgs& a, int cus, hipStream_t stream)
         }
         const size_t smem = (((size_t)16 * (a.Hp + 8) * 2 + 15) / 16) * 16 + 3 * 64 * sizeof(float4);
         if (hk && smem <= 160 * 1024) {
-            SCTC_TRY(prepare_kernel(hk, smem, 2 * nwg, cus, &fits));
-            if (!fits) return not_resident("6..16 utterances, 16-bit state", 2 * nwg, cus);
-            SCTC_HIP_TRY(hipMemsetAsync(a.xbuf, 0xFF, (size_t)2 * a.n_xrows * a.Hp * 2, stream));
-            hipLaunchKernelGGL(hk, dim3(2 * nwg), dim3(256), smem, stream, a);
-            SCTC_HIP_TRY(hipGetLastError());
-            return SCTC_OK;
+            SCTC_TRY(launch_persistent(hk, 2 * nwg, smem, 1, (size_t)2 * a.n_xrows * a.Hp * 2, a, cx, &done));
+            if (done) return SCTC_OK;
         }
     }
     if (a.B > 5 && a.B <= 16 && a.variant != 1) {
@@ -1208,15 +1463,11 @@ static int launch_recurrent_one(const RecArgs& a, int cus, hipStream_t stream)
         }
         const size_t smem = sizeof(float) * ((size_t)16 * (a.Hp + 4) + 3 * 256);
         if (mk && smem <= 160 * 1024) {
-            SCTC_TRY(prepare_kernel(mk, smem, 2 * nwg, cus, &fits));
-            if (!fits) return not_resident("6..16 utterances", 2 * nwg, cus);
-            SCTC_HIP_TRY(hipMemsetAsync(a.xbuf, 0xFF, (size_t)2 * a.n_xrows * a.Hp * sizeof(float), stream));
-            hipLaunchKernelGGL(mk, dim3(2 * nwg), dim3(256), smem, stream, a);
-            SCTC_HIP_TRY(hipGetLastError());
-            return SCTC_OK;
+            SCTC_TRY(launch_persistent(mk, 2 * nwg, smem, 1, (size_t)2 * a.n_xrows * a.Hp * sizeof(float), a, cx, &done));
+            if (done) return SCTC_OK;
         }
     }
-    if (ntiles == 2 && a.variant != 1 && 4 * nwg <= 2 * cus && (4 * nwg) % 8 == 0) {
+    if (ntiles == 2 && a.variant != 1 && 4 * nwg <= 2 * cx.cus && (4 * nwg) % 8 == 0) {
         // two chains per CU; NREG keeps the LDS share of the slab at <= 76 KiB per workgroup
         RecKernel qk = nullptr;
         int ncq = 0, nreg = 0;
@@ -1229,26 +1480,23 @@ static int launch_recurrent_one(const RecArgs& a, int cus, hipStream_t stream)
         }
         if (qk) {
             const size_t smem = sizeof(float4) * ((size_t)4 * (ncq - nreg) * 64 + 3 * 64);
-            SCTC_TRY(prepare_kernel(qk, smem, 4 * nwg, cus, &fits));
-            if (fits) {     // otherwise: the one-workgroup-per-CU kernel below
-                hipLaunchKernelGGL(qk, dim3(4 * nwg), dim3(256), smem, stream, a);
-                SCTC_HIP_TRY(hipGetLastError());
-                return SCTC_OK;
-            }
+            SCTC_TRY(launch_persistent(qk, 4 * nwg, smem, 2, 0, a, cx, &done));
+            if (done) return SCTC_OK;     // otherwise: the one-workgroup-per-CU kernel below
         }
     }
     const int ntw = ntiles <= 2 ? 1 : (ntiles <= 4 ? 2 : 4);
     const size_t smem = sizeof(float4) * ((size_t)nwg * 64 + 2 * ntw * 64);
-    RecKernel kern = ntw == 1 ? pick_kernel<1>(nwg / 2)
-                     : (ntw == 2 ? pick_kernel<2>(nwg / 2) : pick_kernel<4>(nwg / 2));
-    SCTC_TRY(prepare_kernel(kern, smem, 2 * nwg, cus, &fits));
-    if (!fits) return not_resident("flag kernel", 2 * nwg, cus);
-    hipLaunchKernelGGL(kern, dim3(2 * nwg), dim3(256), smem, stream, a);
-    SCTC_HIP_TRY(hipGetLastError());
-    return SCTC_OK;
+    if (smem <= 160 * 1024) {
+        RecKernel kern = ntw == 1 ? pick_kernel<1>(nwg / 2)
+                         : (ntw == 2 ? pick_kernel<2>(nwg / 2) : pick_kernel<4>(nwg / 2));
+        SCTC_TRY(launch_persistent(kern, 2 * nwg, smem, 1, 0, a, cx, &done));
+        if (done) return SCTC_OK;
+    }
+    if (cx.path) *cx.path = REC_PATH_FALLBACK;
+    return launch_fallback(a, stream);
 }
 
-int launch_recurrent(const RecArgs& a_in, hipStream_t stream)
+int launch_recurrent(const RecArgs& a_in, hipStream_t stream, int* path)
 {
     RecArgs a = a_in;
     if (a.poll_delay < 0) a.poll_delay = a.Hp > 1024 ? 5 : 0;
@@ -1259,13 +1507,13 @@ int launch_recurrent(const RecArgs& a_in, hipStream_t stream)
     if ((size_t)a.n_xrows * a.Hp * sizeof(float) >= ((size_t)1 << 31))
         return set_error(SCTC_ERR_ARG, "recurrent kernel: %d exchange rows x %d units exceed the "
                          "2 GiB buffer addressing", a.n_xrows, a.Hp);
-    int dev = 0, cus = 0;
-    SCTC_HIP_TRY(hipGetDevice(&dev));
-    SCTC_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int nwg = a.Hp / 16;
-    if (2 * nwg > cus)
-        return set_error(SCTC_ERR_ARG, "recurrent kernel: needs %d co-resident workgroups, device "
-                         "has %d CUs", 2 * nwg, cus);
+    LaunchCtx cx;
+    cx.stream = stream;
+    cx.path = path;
+    cx.dev = 0;
+    cx.cus = 0;
+    SCTC_HIP_TRY(hipGetDevice(&cx.dev));
+    SCTC_HIP_TRY(hipDeviceGetAttribute(&cx.cus, hipDeviceAttributeMultiprocessorCount, cx.dev));
     // utterances are independent: more than 128 run as consecutive launches of <= 128 (sorted by
     // length, so a later launch covers no more steps than its first utterance has frames)
     constexpr int MAXB = 128;
@@ -1275,7 +1523,7 @@ int launch_recurrent(const RecArgs& a_in, hipStream_t stream)
         c.T_b = a_in.T_b + b0;
         c.B = std::min(MAXB, a_in.B - b0);
         if (a_in.T_host) c.Tmax = std::min(a_in.Tmax, (int)a_in.T_host[b0]);
-        SCTC_TRY(launch_recurrent_one(c, cus, stream));
+        SCTC_TRY(launch_recurrent_one(c, cx));
     }
     return SCTC_OK;
 }

@@ -55,13 +55,16 @@ def allreduce_flat(flat, side, bucket_elems=DEFAULT_BUCKET_ELEMS, group=None):
     return flat, side
 
 
-def allreduce_overlapped(net, side, group=None, side_stream=None):
+def allreduce_overlapped(net, side, group=None, side_stream=None, backward_queued=True):
     """Sum-all-reduce net's flat gradient buffer bucket by bucket WHILE the backward pass queued
     on the current stream is still running: a side stream waits for the event the
     engine records when a layer's gradient is final (output layer first) and starts that layer's
     all-reduce; RCCL moves the finished layers over xGMI while the GEMMs / BPTT of the earlier
     layers compute.  `side` (small 1-D float64 device tensor, e.g. [n_valid, cost_sum, ...]) is
-    reduced last.  On return the CURRENT stream has been made to wait for all of it."""
+    reduced last.  On return the CURRENT stream has been made to wait for all of it.
+    `backward_queued=False`: this rank queued no backward pass this step (empty shard; its gradient
+    buffer was zeroed on the current stream instead) -- the engine's events are then stale or were
+    never recorded, so the side stream is ordered behind the current stream as a whole."""
     import torch
     import torch.distributed as dist
     import _sctc
@@ -73,8 +76,11 @@ def allreduce_overlapped(net, side, group=None, side_stream=None):
     st = side_stream or torch.cuda.Stream()
     works = []
     with torch.cuda.stream(st):
+        if not backward_queued:
+            st.wait_stream(cur)                    # the zero fill, not a stale event, orders the buckets
         for ev, start, end in net.gradBuckets():
-            _sctc.check(L.sctc_stream_wait_event(st.cuda_stream, ev), "stream_wait_event")
+            if backward_queued:
+                _sctc.check(L.sctc_stream_wait_event(st.cuda_stream, ev), "stream_wait_event")
             works.append(dist.all_reduce(flat[start:end], op=dist.ReduceOp.SUM, group=group,
                                          async_op=True))
         st.wait_stream(cur)                        # `side` is produced on the compute stream
@@ -136,5 +142,6 @@ class DataParallel(object):
         if regcost_local is not None:       # 0-dim device tensor (NNet.regCostDev) or a number
             side[2] = regcost_local
             side[3] = 1.0
-        allreduce_overlapped(self.net, side, self.group, self._side_stream)
+        allreduce_overlapped(self.net, side, self.group, self._side_stream,
+                             backward_queued=cost_dev is not None)
         return self._finish(side)

@@ -65,6 +65,8 @@ class NNet:
             self.temporalLayer = -1           # brnnet.py:27-30
         else:
             self.temporalLayer = temporalLayer
+        if reg > 0 and numLayers + 1 > 128:
+            raise ValueError("reg > 0 supports at most 127 layers (bias ranges of the fused L2 step)")
         self.maxAct = 20.0                    # brnnet.py:32
         self._h = None
         self.stack = None
@@ -267,6 +269,15 @@ class NNet:
     def checkAsync(self):
         """synchronises the current stream; raises if a persistent kernel of the queued step timed out"""
         _sctc.check(_sctc.lib().sctc_brnn_check(self._h, _sctc.current_stream_ptr()), "costAndGrad")
+
+    def recurrentPath(self):
+        """(forward, bptt, retries): which recurrence the last step ran -- 1 one persistent launch
+        per pass, 2 the same under the inter-process device lease, 3 one launch per time step (the
+        non-persistent fallback) -- and how many steps of this model were re-run after a timeout"""
+        f, b, r = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        _sctc.check(_sctc.lib().sctc_brnn_recurrent_path(self._h, ctypes.byref(f), ctypes.byref(b),
+                                                         ctypes.byref(r)), "recurrentPath")
+        return f.value, b.value, r.value
 
     def gradBuckets(self):
         """[(event, start, end)] over the flat gradient buffer in the order the backward pass

@@ -34,10 +34,10 @@ class SGD:
         self.model = model
         self.maxBatch = maxBatch
         self.it = 0
-        self.momentum = momentum            # momentum
-        self.alpha = alpha                  # learning rate
+        self.momentum = momentum
+        self.alpha = alpha
         self.optimizer = optimizer
-        self.maxGNorm = maxGradNorm         # gradient clip norm value
+        self.maxGNorm = maxGradNorm
         self.minibatch = int(minibatch)
         if self.optimizer == 'nesterov':
             # sgd.py:21-23 -- one flat buffer with the model's layout
@@ -79,15 +79,17 @@ class SGD:
 
     # ------------------------------------------------------------------ device-side step
 
-    def _grad_sumsq(self, grad_scale=1.0, reg=0.0):
+    def _grad_sumsq(self, grad_scale=1.0, reg=0.0, mom=0.0):
         """|| effective gradient ||^2 on the device.  reg == 0: sum g^2 (the caller scales the norm
-        by grad_scale); reg > 0 (minibatch / data-parallel): sum (grad_scale*g + reg*w)^2 with the
-        L2 term entering exactly once, after the all-reduce (biases excluded, brnnet.py:197-200)"""
+        by grad_scale); reg > 0 (minibatch / data-parallel): sum (grad_scale*g + reg*(w + mom*v))^2
+        with the L2 term entering exactly once, after the all-reduce, evaluated at the look-ahead
+        point like the reference's (sgd.py:91-95, brnnet.py:197-198; biases excluded, :197-200)"""
         g = self.model.grad.flat
         if reg > 0.0:
             nr = self.model.noreg_ranges()
             _sctc.check(_sctc.lib().sctc_sumsq_reg(
-                g.data_ptr(), self.model._params.data_ptr(), float(grad_scale), float(reg),
+                g.data_ptr(), self.model._params.data_ptr(), self.velocity.flat.data_ptr(), float(mom),
+                float(grad_scale), float(reg),
                 g.numel(), _sctc.i64(nr), len(nr) // 2, self._sumsq.data_ptr(),
                 self._ws.data_ptr(), self._ws.numel(), _sctc.current_stream_ptr()), "euclid_norm")
             return
@@ -227,7 +229,7 @@ class SGD:
             return
         grad_scale = 1.0 / n_valid      # mean over non-skipped utterances (1.0 for the reference's B=1)
         # Compute norm of all parameters as one vector (sgd.py:102-107): one reduction
-        self._grad_sumsq(grad_scale, reg_late)
+        self._grad_sumsq(grad_scale, reg_late, mom)
         # the reference's cost includes the L2 cost (brnnet.py:178-183); same convention for
         # every minibatch size (rank-local regcost is identical on all ranks)
         cost = cost_sum / n_valid + (m.regcost if m.reg > 0 else 0.0)

@@ -17,6 +17,7 @@ for p in (ROOT, os.path.join(ROOT, "stanford-ctc_amd")):
 import torch  # noqa: E402
 
 import _sctc  # noqa: E402
+from tools.diag import sctc_diag  # noqa: E402
 
 PHASES = ["fwd_gemm", "fwd_rec", "ctc", "bwd_gemm", "bwd_rec", "other"]
 
@@ -42,7 +43,7 @@ def sec_info():
     print("device:", name.value.decode(), "CUs", cu.value, "LDS/CU", lds.value, "mem GB",
           mem.value / 2 ** 30)
     print("host cores:", os.cpu_count())
-    print("selftest mask:", L.sctc_selftest(None))
+    print("selftest mask:", sctc_diag.lib().sctc_selftest(None))
 
 
 def sec_gemm():
@@ -189,11 +190,11 @@ def sec_twostream():
 
 def sec_fabric():
     """hand-off latencies between workgroups (same XCD / different XCDs)"""
-    L = _sctc.lib()
+    L = sctc_diag.lib()
     for rep in range(2):
         out = (ctypes.c_float * 10)()
         rc = L.sctc_probe_fabric(out, 10, None)
-        assert rc == 0, L.sctc_last_error()
+        assert rc == 0, L.sctc_diag_last_error()
         v = list(out)
         print("partners: same-XCD block %d, cross-XCD block %d" % (v[0], v[1]))
         print("  flag ping-pong us/round trip  same XCD: sc0 %.2f  sc1 %.2f  sc0+sc1 %.2f" % tuple(v[2:5]))
@@ -203,9 +204,9 @@ def sec_fabric():
 
 def sec_mfmarate():
     """sustained fp32 MFMA rate without memory traffic (what the clock under load allows)"""
-    L = _sctc.lib()
+    L = sctc_diag.lib()
     out = (ctypes.c_float * 8)()
-    assert L.sctc_probe_mfma(out, 8, None) == 0, L.sctc_last_error()
+    assert L.sctc_probe_mfma(out, 8, None) == 0, L.sctc_diag_last_error()
     print("pure MFMA loops, 3 waves/SIMD on all CUs, constant operands: 32x32x2 f32 %.1f TFLOP/s (%.2f ms), "
           "16x16x4 f32 %.1f TFLOP/s (%.2f ms); nominal peak 157.3 at 2.4 GHz" % tuple(out[:4]))
     print("   random operands per MFMA group:                         32x32x2 f32 %.1f TFLOP/s (%.2f ms), "

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(sctc):
     for n in names:
         assert hasattr(L, n), "libsctc_hip.so does not export %s" % n
     assert sorted(sctc.PROTOTYPES) == names, "ctypes prototypes out of sync with include/sctc.h"
-    assert L.sctc_abi_version() == 2        # v2: sctc_brnn_config.operand_dtype, gemm_h16, *_reg
+    assert L.sctc_abi_version() == 3        # v3: shared-device mode, recurrent_path; probes moved to tools/diag
 
 
 def test_struct_mirrors_match_the_header(sctc, tmp_path):
@@ -68,9 +68,11 @@ def test_argument_errors_need_no_gpu(sctc):
     assert sizes.param_count == 20 * 30 + 30 + 2 * (30 * 30 + 30) + 30 * 6 + 6 + 2 * 30 * 30
     assert sizes.param_elems == 4 * (32 * 64 + 32) + 2 * 32 * 64
     assert sizes.workspace_bytes > 0
-    bad = sctc.BrnnConfig(20, 6, 4096, 3, 2, 10, 1, 20.0, 0.0, 1)   # needs 512 resident workgroups
+    big = sctc.BrnnConfig(20, 6, 4096, 3, 2, 10, 1, 20.0, 0.0, 1)   # 512 workgroups per pass: cannot be
+    assert L.sctc_brnn_query(ctypes.byref(big), ctypes.byref(sizes)) == 0   # persistent -> per-step launches
+    bad = sctc.BrnnConfig(20, 300, 30, 3, 2, 10, 1, 20.0, 0.0, 1)
     assert L.sctc_brnn_query(ctypes.byref(bad), ctypes.byref(sizes)) == -1
-    assert b"workgroups" in L.sctc_last_error()
+    assert b"alphabet" in L.sctc_last_error()
     with pytest.raises(ValueError):
         sctc.check(-1, "x")
     T = np.array([5], dtype=np.int32)

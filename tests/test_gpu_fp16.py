@@ -185,3 +185,34 @@ def test_fp16_cfg5_full_size(mods):
     np.testing.assert_allclose(c8[sel], cm8, rtol=1e-4)
     assert c1[0] == pytest.approx(cx[0], rel=2e-3)
     np.testing.assert_allclose(c8[sel], cx, rtol=2e-3)
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_fp16_forward_only_model(mods, golden, B):
+    """NNet(fp16=True, train=False) (runNNet.py --test on the fp16 configuration): a forward-only
+    model has no bfloat16 shadow copies, so the input gather must write the float16 shadow only
+    (round 2 aliased the two and the first GEMM read bfloat16 bits as float16: 1.0 became 1.875).
+    Probabilities against the Mixed restatement and against the train=True model's forward."""
+    _, brnnet, obrnn, _ = mods
+    params, grads, dims, data, labels, cost = load_net(golden("brnn_cfg.npz"), "cfg5_")
+    D, A, H, NL, TL, T = dims
+    rs = np.random.RandomState(B)
+    datas = [data] + [rs.randn(D, int(rs.randint(3, T))) for _ in range(B - 1)]
+    net = brnnet.NNet(D, A, H, NL, T, train=False, temporalLayer=TL, maxUtts=B, fp16=True)
+    net.setParams(host_stack(params))
+    probs = net.forwardProbs(datas)
+    for x, p in zip(datas, probs):
+        with np.errstate(all="ignore"):
+            logits, _ = obrnn.forward(params, x, TL, 20.0, obrnn.Mixed(rec=False))
+            p_m = obrnn.softmax_cols(logits)
+            logits_x, _ = obrnn.forward(params, x, TL, 20.0, None)
+            p_x = obrnn.softmax_cols(logits_x)
+        assert p.shape == p_m.shape and p.dtype == np.float32
+        err_m = np.abs(p - p_m).max()
+        err_x = np.abs(p - p_x).max()
+        print("fp16 forward-only B=%d: max |p - Mixed| %.2e, max |p - exact| %.2e" % (B, err_m, err_x))
+        assert err_m < 2e-5, err_m
+        assert err_x < 5e-3, err_x
+    # one utterance through costAndGrad(data) of the forward-only model (brnnet.py:171-173)
+    p1 = net.costAndGrad(datas[0])
+    np.testing.assert_allclose(p1, probs[0], rtol=1e-4, atol=1e-7)

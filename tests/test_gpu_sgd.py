@@ -201,6 +201,62 @@ def test_sgd_l2_term_enters_once(mb):
     assert opt.last_gnorm == pytest.approx(gn, rel=1e-4)
 
 
+@pytest.mark.parametrize("mb", [1, 4])
+def test_sgd_l2_term_at_the_look_ahead_point(mb):
+    """reg > 0 over THREE steps (velocity != 0 from the second step on): the reference evaluates the
+    L2 term reg*W at the Nesterov look-ahead point w + mom*v (sgd.py:91-95 moves the weights there
+    before costAndGrad, brnnet.py:197-198 adds reg*W); the minibatch path, which adds the term after
+    the 1/n_valid scaling with the look-ahead already undone, must use the same point"""
+    from nnets import brnnet
+    import sgd
+    from oracle import brnn as obrnn
+    rs = np.random.RandomState(15)
+    D, A, H, NL, TL, maxT = 10, 6, 32, 2, 1, 24
+    reg, alpha = 0.5, 2e-2                  # a large L2 term: a wrong evaluation point must show
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    for b in params["b"]:
+        b += rs.randn(*b.shape)
+    keys = ["k%d" % i for i in range(3 * mb)]
+    data_dict = {k: rs.randn(D, int(rs.randint(10, maxT))).astype(np.float32) for k in keys}
+    alis = {k: [str(v) for v in rs.randint(1, A, size=2)] for k in keys}
+    net = brnnet.NNet(D, A, H, NL, maxT, temporalLayer=TL, maxUtts=mb, reg=reg)
+    st = [[w, b] for w, b in zip(params["W"], params["b"])] + [[params["Wf"], None], [params["Wb"], None]]
+    net.setParams(st)
+    opt = sgd.SGD(net, maxT, alpha=alpha, momentum=0.9, maxGradNorm=1e9, minibatch=mb)
+    random.seed(5)
+    order = list(keys)
+    opt.run(data_dict, alis, order)
+    assert opt.it == 3
+    w = flat(params).astype(np.float64)
+    v = np.zeros_like(w)
+    w_plain = w.copy()                      # the same loop with reg*W taken at w (the old behaviour)
+    v_plain = v.copy()
+    mom = 0.5
+    with np.errstate(all="ignore"):
+        for i in range(0, len(order), mb):
+            ks = order[i:i + mb]
+            xs = [data_dict[k] for k in ks]
+            ls = [np.array(alis[k], dtype=np.int32) for k in ks]
+            _, g, _, n_valid = obrnn.cost_and_grad_batch(unflat(w + mom * v, params), xs, ls, TL, reg=reg, mean=True)
+            assert n_valid == mb
+            v = mom * v - alpha * gflat(g)
+            w = w + v
+            _, g0, _, _ = obrnn.cost_and_grad_batch(unflat(w_plain + mom * v_plain, params), xs, ls, TL, reg=0.0, mean=True)
+            _, gr, _, _ = obrnn.cost_and_grad_batch(unflat(w_plain, params), xs, ls, TL, reg=reg, mean=True)
+            _, gn, _, _ = obrnn.cost_and_grad_batch(unflat(w_plain, params), xs, ls, TL, reg=0.0, mean=True)
+            v_plain = mom * v_plain - alpha * (gflat(g0) + gflat(gr) - gflat(gn))
+            w_plain = w_plain + v_plain
+    got = np.concatenate([np.concatenate([net.stack[i][0].copy_to_host().ravel(),
+                                          net.stack[i][1].copy_to_host().ravel()])
+                          for i in range(NL + 1)] +
+                         [net.stack[NL + 1][0].copy_to_host().ravel(),
+                          net.stack[NL + 2][0].copy_to_host().ravel()])
+    err = np.linalg.norm(got - w) / np.linalg.norm(w)
+    wrong = np.linalg.norm(w_plain - w) / np.linalg.norm(w)
+    assert wrong > 50 * max(err, 1e-7), (err, wrong)      # the test can tell the two apart
+    assert err < 5e-6, err
+
+
 def test_reference_py2_checkpoint_loads(golden):
     """a params.pk in the reference's own byte format (Python-2 cPickle protocol 0,
     sgd.py:36-42 + brnnet.py:258-267; tests/golden/ref_py2_params.pk) resumes: SGD state and

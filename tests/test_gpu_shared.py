@@ -1,0 +1,178 @@
+"""The recurrence when the device is NOT exclusively ours.
+
+The reference's per-step launches (ctc_fast/nnets/brnnet.py:148-152, :215-224) run on any GPU,
+busy or not.  The persistent kernels that replace them need every workgroup of a pass resident at
+once, so the library carries three guards (csrc/recurrent.hip "co-residency guards"): an
+inter-process device lease, a per-step non-persistent fallback, and an automatic re-run of a step
+whose persistent launch timed out.  These tests drive each of them on the one GPU of the box."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_brnn import _all_grads, check_grads, make_net, rel
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import _sctc
+    from nnets import brnnet
+    from oracle import brnn as obrnn
+    return _sctc, brnnet, obrnn, torch
+
+
+def _problem(obrnn, seed, D, A, H, NL, TL, Ts):
+    rs = np.random.RandomState(seed)
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 8)).astype(np.int32) for T in Ts]
+    return params, datas, labs
+
+
+@pytest.mark.parametrize("H,B", [(96, 3), (512, 3), (512, 11), (512, 24), (1824, 6)])
+def test_per_step_fallback_vs_persistent_and_oracle(mods, monkeypatch, H, B):
+    """SCTC_REC_VARIANT=3 forces the non-persistent recurrence (one launch per time step, the
+    reference's own structure): ragged minibatches against the persistent kernels of every size
+    class (1..5, 6..16, 17..32 utterances) and, at the small layer sizes, the float64 oracle"""
+    _, brnnet, obrnn, _ = mods
+    D, A, NL, TL = 24, 12, 3, 2
+    rs = np.random.RandomState(7 * H + B)
+    Ts = [int(t) for t in rs.randint(2, 26, size=B)]
+    Ts[0] = 26
+    Ts[-1] = 1
+    params, datas, labs = _problem(obrnn, H + B, D, A, H, NL, TL, Ts)
+    net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
+    costs, _, skips = net.costAndGradBatch(datas, labs)
+    assert net.recurrentPath() == (1, 1, 0)
+    g_p = _all_grads(net, NL)
+    monkeypatch.setenv("SCTC_REC_VARIANT", "3")
+    net3 = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
+    costs3, _, skips3 = net3.costAndGradBatch(datas, labs)
+    assert net3.recurrentPath() == (3, 3, 0)
+    np.testing.assert_array_equal(skips, skips3)
+    np.testing.assert_allclose(costs3[~skips], costs[~skips], rtol=1e-5)
+    for a, b in zip(g_p, _all_grads(net3, NL)):
+        assert rel(b, a) < 1e-4
+    g3 = _all_grads(net3, NL)
+    net3.costAndGradBatch(datas, labs)
+    for a, b in zip(g3, _all_grads(net3, NL)):
+        np.testing.assert_array_equal(a, b)          # run-to-run reproducible
+    if H <= 512:
+        with np.errstate(all="ignore"):
+            costs_ref, g_ref, skips_ref, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+        np.testing.assert_array_equal(skips3, skips_ref)
+        np.testing.assert_allclose(costs3[~skips_ref], costs_ref[~skips_ref], rtol=1e-4)
+        check_grads(net3, g_ref, NL)
+    # forward-only model on the fallback
+    netf = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, train=False, maxUtts=B)
+    monkeypatch.delenv("SCTC_REC_VARIANT")
+    netp = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, train=False, maxUtts=B)
+    for pf, pp in zip(netf.forwardProbs(datas), netp.forwardProbs(datas)):
+        np.testing.assert_allclose(pf, pp, rtol=1e-4, atol=1e-7)
+    assert netf.recurrentPath()[0] == 3 and netp.recurrentPath()[0] == 1
+
+
+def test_layer_wider_than_the_device_runs_per_step(mods):
+    """H = 2304 needs 2 x 144 = 288 co-resident workgroups on a 256-CU part: rounds 1-2 rejected
+    such layers, now they run on the per-step recurrence (the reference has no such limit:
+    debug-utils/profileNNet.py uses whatever --layerSize says)"""
+    _, brnnet, obrnn, _ = mods
+    D, A, H, NL, TL = 16, 9, 2304, 2, 1
+    Ts = [7, 5, 2]
+    params, datas, labs = _problem(obrnn, 99, D, A, H, NL, TL, Ts)
+    with np.errstate(all="ignore"):
+        costs_ref, g_ref, skips_ref, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+    net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=len(Ts))
+    costs, _, skips = net.costAndGradBatch(datas, labs)
+    assert net.recurrentPath() == (3, 3, 0)
+    np.testing.assert_array_equal(skips, skips_ref)
+    np.testing.assert_allclose(costs[~skips_ref], costs_ref[~skips_ref], rtol=1e-4)
+    check_grads(net, g_ref, NL)
+
+
+@pytest.mark.parametrize("B", [2, 8, 20])
+def test_device_lease_is_bit_identical(mods, B):
+    """shared-device mode runs the SAME persistent kernels, only under the inter-process lease
+    (flock on /dev/shm/sctc_gpu_<pci>.lock) and synchronously: results are bit-identical"""
+    _sctc, brnnet, obrnn, _ = mods
+    D, A, H, NL, TL = 24, 12, 512, 2, 1
+    rs = np.random.RandomState(B)
+    Ts = [int(t) for t in rs.randint(3, 30, size=B)]
+    params, datas, labs = _problem(obrnn, 3 * B, D, A, H, NL, TL, Ts)
+    net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
+    costs, _, _ = net.costAndGradBatch(datas, labs)
+    g = _all_grads(net, NL)
+    L = _sctc.lib()
+    assert L.sctc_shared_device() == 0
+    L.sctc_set_shared_device(1)
+    try:
+        costs2, _, _ = net.costAndGradBatch(datas, labs)
+        assert net.recurrentPath() == (2, 2, 0)
+        assert any(f.startswith("sctc_gpu_") for f in os.listdir("/dev/shm"))
+    finally:
+        L.sctc_set_shared_device(0)
+    np.testing.assert_array_equal(costs, costs2)
+    for a, b in zip(g, _all_grads(net, NL)):
+        np.testing.assert_array_equal(a, b)
+    net.costAndGradBatch(datas, labs)
+    assert net.recurrentPath() == (1, 1, 0)
+
+
+def _hammer(n_procs, steps, B, T, tmp_path, env_extra, tag):
+    sync = tmp_path / ("sync_" + tag)
+    sync.mkdir()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SCTC_SHARED_DEVICE", None)
+    env.update(env_extra)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gpu_hammer.py"), str(steps), str(B),
+                               str(T), str(sync), "p%d" % i], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for i in range(n_procs)]
+    import time
+    t0 = time.time()
+    while not all((sync / ("p%d.ready" % i)).exists() for i in range(n_procs)):
+        assert all(p.poll() is None for p in procs), [p.communicate() for p in procs if p.poll() is not None]
+        assert time.time() - t0 < 900, "hammer processes never became ready"
+        time.sleep(0.01)
+    (sync / "go").write_text("go")
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, so[-1500:] + se[-3000:]
+        outs.append(json.loads([l for l in so.splitlines() if l.startswith("{")][-1]))
+    return outs
+
+
+@pytest.mark.parametrize("mode", ["lease", "recover"])
+def test_two_processes_hammer_one_gpu(tmp_path, mode):
+    """Two processes hammer costAndGradBatch(B=6, H=1824) on ONE GPU concurrently for 50 steps --
+    each step launches two 228-workgroup persistent grids per process, the situation that
+    dead-locked round 2's 2-rank bench rehearsal.  `lease`: SCTC_SHARED_DEVICE=1, the processes take
+    turns, every step bit-identical to a solo run.  `recover`: nothing set -- a process whose
+    persistent launch times out switches the lease on by itself and re-runs the step (under the
+    lease: bit-identical; on the per-step fallback: same tolerance as the fallback test)."""
+    import torch
+    assert torch.cuda.is_available()
+    steps, B, T = 50, 6, 40
+    solo = _hammer(1, steps, B, T, tmp_path, {}, "solo")[0]
+    assert solo["path"] == [1, 1] and solo["retries"] == 0 and solo["shared_mode"] == 0
+    extra = {"SCTC_SHARED_DEVICE": "1"} if mode == "lease" else {}
+    outs = _hammer(2, steps, B, T, tmp_path, extra, mode)
+    for o in outs:
+        np.testing.assert_allclose(np.array(o["costs"]), np.array(solo["costs"]), rtol=1e-5)
+        if mode == "lease":
+            assert o["path"] == [2, 2] and o["retries"] == 0
+            assert o["digests"] == solo["digests"]
+        else:
+            same = sum(a == b for a, b in zip(o["digests"], solo["digests"]))
+            print("recover: %s retries %d, final path %s, shared_mode %d, %d/%d steps bit-identical, %.2f s"
+                  % (o["tag"], o["retries"], o["path"], o["shared_mode"], same, steps, o["seconds"]))
+            if o["retries"] == 0:
+                assert o["digests"] == solo["digests"]

@@ -4,7 +4,7 @@
 // cache-scope encoding of the polling load (sc0 / sc1 / sc0+sc1), and a 1 KiB "tagged
 // payload" hand-off (every 16-byte granule carries its own sequence number, no separate flag).
 // Diagnostics only (tests/gpu_diag.py fabric); results feed DESIGN.md 4.2.
-#include "common.h"
+#include "diag_common.h"
 
 namespace sctc {
 

@@ -1,0 +1,31 @@
+/*
+ * sctc_diag.h -- C ABI of libsctc_diag.so: hardware probes used while developing and measuring
+ * the kernels of libsctc_hip.so.  NOT part of the drop-in boundary (include/sctc.h): nothing in
+ * stanford-ctc_amd/ loads this library; tests/gpu_diag.py, bench.py's "sustained peak" note and
+ * __graft_entry__.smoke() do.  These entry points allocate (and free) their own scratch memory.
+ */
+#ifndef SCTC_DIAG_H_
+#define SCTC_DIAG_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* sctc_diag_last_error(void);
+/* runs the cross-lane / MFMA fragment-layout probes the kernels rely on; 0 = all as expected,
+ * else a bitmask of the failed probes */
+int sctc_selftest(void* stream);
+/* hand-off latencies between workgroups on the same / on different XCDs (flag ping-pong per
+ * polling-load scope, 1 KiB tagged payload).  results_host[10]: partner block ids (same, cross
+ * XCD), then microseconds per round trip: same-XCD {sc0, sc1, sc0+sc1}, cross-XCD {sc0, sc1,
+ * sc0+sc1}, tagged payload {same, cross}; -1 = timed out (a scope that never observes the store) */
+int sctc_probe_fabric(float* results_host, int32_t n_results, void* stream);
+/* sustained fp32 matrix-pipe rate of register-only MFMA loops on every SIMD: results_host[8] =
+ * {TFLOP/s, ms} for v_mfma_f32_32x32x2_f32 and v_mfma_f32_16x16x4_f32 with constant operands,
+ * then the same two with fresh random operands per MFMA group */
+int sctc_probe_mfma(float* results_host, int32_t n_results, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

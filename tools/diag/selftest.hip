@@ -3,7 +3,7 @@
 // gather, readlane broadcast, and the operand/accumulator lane maps of the two
 // f32 MFMA shapes used by the BRNN kernels (asymmetric operands, so a transposed
 // map cannot pass).  Returns a bitmask of failed probes (0 = all good).
-#include "common.h"
+#include "diag_common.h"
 #include "xlane.h"
 
 namespace sctc {
