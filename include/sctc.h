@@ -235,6 +235,12 @@ int sctc_brnn_forward(sctc_brnn_t h, const sctc_minibatch* mb, float* probs_dev,
 #define SCTC_PHASE_OTHER 5
 #define SCTC_N_PHASES 6
 int sctc_brnn_set_profiling(sctc_brnn_t h, int32_t enable);
+/* diagnostics only: device pointer / shape of an internal fp32 matrix of the last call (which:
+ * 0..numLayers = hActs[i] (0 = the packed input), 100 / 101 = hActsFor / hActsBack, 200 = the delta
+ * entering layer 1); rows follow the packed time-major layout (one utterance: row t = frame t).
+ * Lets a test separate the error of one contraction from the error of its operands. */
+int sctc_brnn_debug_buffer(sctc_brnn_t h, int32_t which, void** dev_ptr, int64_t* rows, int64_t* cols,
+                           int64_t* ld);
 /* diagnostics only: per-step s_memtime stamps of the recurrent kernel when SCTC_REC_DEBUG=1 */
 int sctc_brnn_debug_read(sctc_brnn_t h, uint32_t* out, int32_t n_words);
 int sctc_brnn_phase_ms(sctc_brnn_t h, float* ms_out /* [SCTC_N_PHASES] */);

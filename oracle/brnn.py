@@ -118,25 +118,32 @@ def forward(params, data, temporal_layer, max_act=20.0, mixed=None):
     TL = temporal_layer if 0 < temporal_layer < NL else -1
     T = data.shape[1]
     acts = [np.asarray(data, dtype=np.float64)]
-    hF = hB = None
+    hF = hB = preF = preB = None
+    pre = [None]                      # pre-activations (before ReLU / clip): how close to a kink?
     for i in range(1, NL + 2):
         z = mp.fwd(W[i - 1], acts[i - 1]) + b[i - 1]
+        pre.append(z)
         if i == TL:
             Wf, Wb = params["Wf"], params["Wb"]
             hF = np.zeros_like(z)
             hB = np.zeros_like(z)
+            preF = np.array(z)
+            preB = np.array(z)
             hF[:, 0] = _clip(z[:, 0], max_act)
             hB[:, T - 1] = _clip(z[:, T - 1], max_act)
             for t in range(1, T):
-                hF[:, t] = _clip(z[:, t] + mp.rec_fwd(Wf, hF[:, t - 1]), max_act)
+                preF[:, t] = z[:, t] + mp.rec_fwd(Wf, hF[:, t - 1])
+                hF[:, t] = _clip(preF[:, t], max_act)
                 u = T - 1 - t
-                hB[:, u] = _clip(z[:, u] + mp.rec_fwd(Wb, hB[:, u + 1]), max_act)
+                preB[:, u] = z[:, u] + mp.rec_fwd(Wb, hB[:, u + 1])
+                hB[:, u] = _clip(preB[:, u], max_act)
             acts.append(hF + hB)
         elif i <= NL:
             acts.append(np.maximum(z, 0.0))
         else:
             acts.append(z)
-    return acts[-1], {"acts": acts, "hF": hF, "hB": hB, "TL": TL, "NL": NL}
+    return acts[-1], {"acts": acts, "hF": hF, "hB": hB, "TL": TL, "NL": NL, "pre": pre,
+                      "preF": preF, "preB": preB}
 
 
 def softmax_cols(logits):
@@ -144,14 +151,23 @@ def softmax_cols(logits):
     return e / e.sum(axis=0, keepdims=True)
 
 
-def cost_and_grad(params, data, labels, temporal_layer, max_act=20.0, reg=0.0, blank=0, mixed=None):
+def cost_and_grad(params, data, labels, temporal_layer, max_act=20.0, reg=0.0, blank=0, mixed=None,
+                  masks=None, cache_out=None):
     """One utterance.  Returns (cost, grads, skip, probs) with ``grads`` shaped
     like ``params`` (dW list, db list, dWf, dWb).  On skip, grads is None (the
-    reference returns its stale buffers, brnnet.py:185-186)."""
+    reference returns its stale buffers, brnnet.py:185-186).
+    Test instrumentation (not reference behaviour): ``masks`` = {"relu": {layer: (H,T) 0/1},
+    "F": (H,T), "B": (H,T)} replaces the backward pass's own ReLU / (0,maxAct) masks -- a
+    float32 device and this float64 restatement put a unit whose pre-activation is a rounding
+    error away from a kink on different sides, and the two gradients then differ by that unit's
+    whole delta; with the device's masks imposed, what is left is smooth arithmetic error.
+    ``cache_out`` (a dict) receives the forward cache and "d1", the delta entering layer 1."""
     mp = mixed or _Exact
     W = params["W"]
     logits, cache = forward(params, data, temporal_layer, max_act, mixed)
     acts, hF, hB, TL, NL = cache["acts"], cache["hF"], cache["hB"], cache["TL"], cache["NL"]
+    if cache_out is not None:
+        cache_out.update(cache)
     T = data.shape[1]
     probs = softmax_cols(logits)
     cost, delta, skip = octc.ctc_loss(np.asfortranarray(probs),
@@ -179,6 +195,9 @@ def cost_and_grad(params, data, labels, temporal_layer, max_act=20.0, reg=0.0, b
         if i == TL:
             Wf, Wb = params["Wf"], params["Wb"]
             mF, mB = _open_mask(hF, max_act), _open_mask(hB, max_act)
+            if masks is not None:
+                mF = np.asarray(masks["F"], dtype=np.float64)
+                mB = np.asarray(masks["B"], dtype=np.float64)
             dF = np.array(d_out)
             dB = np.array(d_out)
             dF[:, T - 1] *= mF[:, T - 1]
@@ -194,8 +213,11 @@ def cost_and_grad(params, data, labels, temporal_layer, max_act=20.0, reg=0.0, b
                 dWb = dWb + reg * Wb
             d_out = dF + dB
         else:
-            d_out = d_out * (acts[i] > 0.0)               # sign(h) for h >= 0, brnnet.py:236
+            m = (acts[i] > 0.0) if masks is None else np.asarray(masks["relu"][i], dtype=np.float64)
+            d_out = d_out * m                             # sign(h) for h >= 0, brnnet.py:236
         d_in = d_out
+    if cache_out is not None:
+        cache_out["d1"] = d_in
     grads = {"W": dW, "b": db, "Wf": dWf, "Wb": dWb}
     return cost, grads, False, probs
 

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "sctc_brnn_forward": (ctypes.c_int, [vp, ctypes.POINTER(Minibatch), vp, vp]),
     "sctc_brnn_set_profiling": (ctypes.c_int, [vp, ctypes.c_int32]),
     "sctc_brnn_debug_read": (ctypes.c_int, [vp, vp, ctypes.c_int32]),
+    "sctc_brnn_debug_buffer": (ctypes.c_int, [vp, ctypes.c_int32, ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p]),
     "sctc_brnn_phase_ms": (ctypes.c_int, [vp, c_f32p]),
     "sctc_brnn_flops": (ctypes.c_int, [vp, ctypes.POINTER(Minibatch), c_f64p, c_f64p, c_f64p]),
     "sctc_gemm_f32": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int32, vp, ctypes.c_int64,

@@ -109,6 +109,7 @@ struct sctc_brnn {
     int rec_force_fallback = 0;   // set while a timed-out step is retried on the per-step fallback
     int rec_path[2] = {0, 0};     // REC_PATH_* of the last forward / BPTT recurrence
     int rec_retries = 0;          // steps of this handle that were re-run after SCTC_ERR_TIMEOUT
+    const float* last_delta1 = nullptr;   // delta entering layer 1 (A operand of the dW1 GEMM) of the last backward pass
     // host staging of the CTC descriptors (must outlive the async uploads)
     void* ctc_stage = nullptr;
     std::vector<int32_t> ctc_U, ctc_labels;
@@ -809,6 +810,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
         d_in_ld = LD(h->Hp);
         which ^= 1;
     }
+    h->last_delta1 = d_in;
     return SCTC_OK;
 }
 
@@ -1053,6 +1055,29 @@ int sctc_brnn_debug_read(sctc_brnn_t h, uint32_t* out, int32_t n_words)
 {
     SCTC_CHECK_ARG(h && out && n_words >= 0 && n_words <= 2 * REC_DEBUG_WORDS, "debug_read: bad argument");
     SCTC_HIP_TRY(hipMemcpy(out, h->rec_debug, sizeof(uint32_t) * n_words, hipMemcpyDeviceToHost));
+    return SCTC_OK;
+}
+
+/* diagnostics: device pointers to the engine's internal matrices of the LAST call (packed
+ * time-major rows: frame t of the utterance with length rank b is row rowbase[t] + b; one
+ * utterance: row t) */
+int sctc_brnn_debug_buffer(sctc_brnn_t h, int32_t which, void** dev_ptr, int64_t* rows, int64_t* cols,
+                           int64_t* ld)
+{
+    SCTC_CHECK_ARG(h && dev_ptr && rows && cols && ld, "debug_buffer: null argument");
+    const float* p = nullptr;
+    int64_t c = h->Hp, l = LD(h->Hp);
+    if (which >= 0 && which <= h->NL) {
+        p = h->act[which];
+        if (which == 0) { c = h->Dp; l = LD(h->Dp); }
+    } else if (which == 100) p = h->hF;
+    else if (which == 101) p = h->hB;
+    else if (which == 200) p = h->last_delta1;
+    SCTC_CHECK_ARG(p, "debug_buffer: no buffer %d (layers 0..%d, 100 hF, 101 hB, 200 delta_1)", which, h->NL);
+    *dev_ptr = (void*)p;
+    *rows = h->N;
+    *cols = c;
+    *ld = l;
     return SCTC_OK;
 }
 

@@ -279,6 +279,18 @@ class NNet:
                                                          ctypes.byref(r)), "recurrentPath")
         return f.value, b.value, r.value
 
+    def debugBuffer(self, which):
+        """diagnostics: host copy (float64, [rows][cols]) of an internal matrix of the last call --
+        which: 0..numLayers = hActs[i], 100 / 101 = hActsFor / hActsBack, 200 = delta entering layer 1"""
+        torch = _sctc.require_gpu()
+        ptr, rows, cols, ld = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _sctc.check(_sctc.lib().sctc_brnn_debug_buffer(self._h, which, ctypes.byref(ptr), ctypes.byref(rows),
+                                                       ctypes.byref(cols), ctypes.byref(ld)), "debugBuffer")
+        torch.cuda.synchronize()
+        off = (ptr.value - self._ws.data_ptr()) // 4
+        flat = self._ws.view(torch.float32)[off:off + rows.value * ld.value]
+        return flat.view(rows.value, ld.value)[:, :cols.value].cpu().numpy().astype(np.float64)
+
     def gradBuckets(self):
         """[(event, start, end)] over the flat gradient buffer in the order the backward pass
         finishes them (output layer first, brnnet.py:191-193; the recurrent pair right after the

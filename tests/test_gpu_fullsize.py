@@ -192,3 +192,110 @@ def test_cfg5_long_utterances(mods):
     print("cfg5 8 vs 1+7 accumulate:", {k: "%.1e" % v for k, v in worst.items()})
     assert within_tol(worst), worst
     assert all(np.isfinite(v).all() for v in g1.values())
+
+
+@pytest.mark.parametrize("gemm", ["f32", "bf16x3"])
+def test_cfg2_timit_shape_full_size(mods, gemm):
+    """BASELINE configs[1] at its real size: T=300, A=62, 3x1024, temporalLayer 2, inputDim 943
+    (timit-utils/runTimit.sh:21), U=30, minibatch 1 -- the reference's own mode.  Exercises, at
+    size and together, what only twins covered before: brnn_recurrent_s_kernel<32,4>, an alphabet
+    of 62 (one column tile, 64 padded) and split-K in the forward GEMMs (300 rows)."""
+    brnnet, obrnn, torch = mods
+    D, A, H, NL, TL, T, U = 943, 62, 1024, 3, 2, 300, 30
+    rs = np.random.RandomState(2)
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    data = rs.randn(D, T).astype(np.float32)
+    labels = rs.randint(1, A, size=U).astype(np.int32)
+    net = make_net(brnnet, (D, A, H, NL, TL, T), params, gemm=gemm)
+    cost, _, skip = net.costAndGrad(data, labels)
+    assert not skip and net.recurrentPath() == (1, 1, 0)
+    got = tensors(net, NL)
+    with np.errstate(all="ignore"):
+        c_ref, g_ref, s_ref, probs_ref = obrnn.cost_and_grad(params, data.astype(np.float64), labels, TL, 20.0)
+    assert not s_ref
+    assert cost == pytest.approx(c_ref, rel=1e-4)
+    want = oracle_tensors(g_ref, NL)
+    worst = {k: rel(got[k], want[k]) for k in want}
+    print("cfg2 full size gemm=%s: cost rel err %.2e; gradient rel-norm errors:" % (gemm, abs(cost - c_ref) / c_ref),
+          {k: "%.1e" % v for k, v in worst.items()})
+    assert within_tol(worst), worst
+    # bit-reproducible; the forward-only model gives the oracle's probabilities
+    net.costAndGrad(data, labels)
+    again = tensors(net, NL)
+    for k in got:
+        np.testing.assert_array_equal(got[k], again[k])
+    netf = make_net(brnnet, (D, A, H, NL, TL, T), params, train=False, gemm=gemm)
+    p = netf.costAndGrad(data)
+    assert p.shape == (A, T) and np.abs(p - probs_ref).max() < 1e-5
+
+
+def test_cfg4_input_layer_gradient_error_decomposed(mods):
+    """Why dW1 = delta_1 . X^T is the one tensor whose distance to the float64 oracle is ~1e-3
+    (SWBD shape, T=2000) when every other tensor is within 1e-4, taken apart with the engine's
+    own operands (sctc_brnn_debug_buffer):
+      (1) the dW1 contraction ITSELF: device dW1 against the float64 product of the device's own
+          delta_1 and X -- fp32 accumulation over 2000 frames, must be <= 2e-5;
+      (2) ReLU / (0,maxAct) decisions: a unit whose pre-activation is a rounding error away from
+          the kink lands on different sides in float32 and float64; its delta is then present on
+          one side and absent on the other.  The flips are counted, every flipped unit is shown
+          to sit on the kink (|pre-activation| tiny against the layer's scale), and
+      (3) with the DEVICE's masks imposed on the oracle's backward pass every tensor, dW1
+          included, agrees to 3e-4: what separates the two implementations is the placement of
+          tied units, not arithmetic quality (the reference's cudamat-vs-rnnetcpu comparison,
+          debug-utils/checkgrads.py:20-40, has the same property)."""
+    brnnet, obrnn, torch = mods
+    D, A, H, NL, TL, T, U = 615, 33, 1824, 5, 3, 2000, 200
+    rs = np.random.RandomState(4)
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    data = rs.randn(D, T).astype(np.float32)
+    labels = rs.randint(1, A, size=U).astype(np.int32)
+    net = make_net(brnnet, (D, A, H, NL, TL, T), params)
+    cost, _, skip = net.costAndGrad(data, labels)
+    assert not skip
+    got = tensors(net, NL)
+    X = net.debugBuffer(0)[:, :D]                     # [T][D]
+    d1 = net.debugBuffer(200)[:, :H]                  # [T][H]
+    np.testing.assert_array_equal(X, data.T.astype(np.float64))
+    # (1) the contraction alone
+    dW1_64 = d1.T @ X
+    e_gemm = rel(got["W1"], dW1_64)
+    # (2) masks of the device
+    acts = {i: net.debugBuffer(i)[:, :H].T for i in range(1, NL + 1) if i != TL}
+    hF, hB = net.debugBuffer(100)[:, :H].T, net.debugBuffer(101)[:, :H].T
+    masks = {"relu": {i: (a > 0.0).astype(np.float64) for i, a in acts.items()},
+             "F": ((hF > 0.0) & (hF < 20.0)).astype(np.float64),
+             "B": ((hB > 0.0) & (hB < 20.0)).astype(np.float64)}
+    cache = {}
+    with np.errstate(all="ignore"):
+        c_ref, g_ref, s_ref, _ = obrnn.cost_and_grad(params, data.astype(np.float64), labels, TL, 20.0,
+                                                     cache_out=cache)
+        c_m, g_m, s_m, _ = obrnn.cost_and_grad(params, data.astype(np.float64), labels, TL, 20.0, masks=masks)
+    assert not s_ref and not s_m and cost == pytest.approx(c_ref, rel=1e-4)
+    flips, worst_tie = {}, 0.0
+    for i, a in acts.items():
+        o = cache["acts"][i] > 0.0
+        f = o != (a > 0.0)
+        flips["relu%d" % i] = int(f.sum())
+        if f.any():
+            worst_tie = max(worst_tie, float(np.abs(cache["pre"][i][f]).max() / np.abs(cache["pre"][i]).std()))
+    for name, h_dev, h_or, pre in (("F", hF, cache["hF"], cache["preF"]), ("B", hB, cache["hB"], cache["preB"])):
+        o = (h_or > 0.0) & (h_or < 20.0)
+        f = o != (masks[name] > 0.5)
+        flips["rec" + name] = int(f.sum())
+        if f.any():
+            tie = np.minimum(np.abs(pre[f]), np.abs(pre[f] - 20.0))
+            worst_tie = max(worst_tie, float(tie.max() / np.abs(pre).std()))
+    n_units = sum(a.size for a in acts.values()) + 2 * hF.size
+    want, want_m = oracle_tensors(g_ref, NL), oracle_tensors(g_m, NL)
+    worst = {k: rel(got[k], want[k]) for k in want}
+    worst_m = {k: rel(got[k], want_m[k]) for k in want_m}
+    d1_err = rel(d1.T, cache["d1"])
+    print("cfg4 B=1 dW1 decomposition: GEMM alone %.1e | delta_1 vs oracle %.1e | mask flips %s of %d units "
+          "(farthest flipped unit %.1e layer-sigmas from its kink) | vs oracle: W1 %.1e worst other %.1e | "
+          "vs oracle with the device's masks: W1 %.1e worst other %.1e"
+          % (e_gemm, d1_err, flips, n_units, worst_tie, worst["W1"], max(v for k, v in worst.items() if k != "W1"),
+             worst_m["W1"], max(v for k, v in worst_m.items() if k != "W1")))
+    assert e_gemm < 2e-5, e_gemm
+    assert sum(flips.values()) <= 1e-4 * n_units and worst_tie < 1e-4, (flips, worst_tie)
+    assert all(v < TOL_DEFAULT for v in worst_m.values()), worst_m
+    assert within_tol(worst), worst
