@@ -93,7 +93,7 @@ def _oracle_chunk(idx):
     """worker of oracle_parallel: the utterances `idx` of the inherited problem; returns their
     costs / skips and the SUM of their gradients (one pickled gradient per worker, not per
     utterance)"""
-    params, datas, labs, TL, max_act, want_grad, mixed_rec = _ORACLE_CTX
+    params, datas, labs, TL, max_act, want_grad, mixed_rec, masks_of = _ORACLE_CTX
     from oracle import brnn as obrnn
     mixed = None if mixed_rec is None else obrnn.Mixed(rec=mixed_rec)
     from oracle import ctc as octc
@@ -108,7 +108,8 @@ def _oracle_chunk(idx):
         for i in idx:
             data = np.asarray(datas[i], dtype=np.float64)
             if want_grad:
-                c, g, s, _ = obrnn.cost_and_grad(params, data, labs[i], TL, max_act, mixed=mixed)
+                c, g, s, _ = obrnn.cost_and_grad(params, data, labs[i], TL, max_act, mixed=mixed,
+                                                 masks=masks_of(i) if masks_of else None)
             else:
                 logits, _ = obrnn.forward(params, data, TL, max_act, mixed)
                 c, _, s = octc.ctc_loss(np.asfortranarray(obrnn.softmax_cols(logits)),
@@ -136,17 +137,19 @@ def job_threads():
 
 
 def oracle_parallel(params, datas, labs, TL, max_act=20.0, want_grad=True, procs=None,
-                    mixed_rec=None):
+                    mixed_rec=None, masks_of=None):
     """the float64 oracle over a list of utterances in forked worker processes (a few BLAS
     threads each): the full-size configurations take seconds instead of minutes on the GPU
     box's host.  Returns (costs, summed gradient dict or None, skips).  mixed_rec: None = exact
-    float64; True / False = oracle.brnn.Mixed(rec=...) (the 16-bit-operand numerics)."""
+    float64; True / False = oracle.brnn.Mixed(rec=...) (the 16-bit-operand numerics).  masks_of:
+    callable i -> the ReLU / (0,maxAct) masks utterance i's backward pass must use (the device's own
+    decisions, oracle.brnn.cost_and_grad `masks`); evaluated inside the workers."""
     global _ORACLE_CTX
     import multiprocessing as mp
     import os
     n = len(datas)
     procs = procs or max(1, min(n, 16, (os.cpu_count() or 8) // job_threads()))
-    _ORACLE_CTX = (params, datas, labs, TL, max_act, want_grad, mixed_rec)
+    _ORACLE_CTX = (params, datas, labs, TL, max_act, want_grad, mixed_rec, masks_of)
     chunks = [list(range(k, n, procs)) for k in range(procs)]
     try:
         if procs == 1:

@@ -8,20 +8,43 @@ production size (GPU fp32 vs CPU fp64, same weights, same data):
   cfg-5  T=8000 A=33 7x2048 TL=4 D=615 U=800, minibatch 1 and 8
 
 Stated tolerances (fp32 device arithmetic, fp64 oracle): cost 1e-4 relative (north_star; observed
-<= 2e-8); gradients, relative Frobenius norm per tensor: 3e-4 (observed <= 1e-4), except the
-input-layer weight gradient dW1 = delta_1 . X^T at 3e-3 (observed 6e-4 at 32 000 frames, 1.2e-3
-at 8 000..64 000 frames of T=2000 utterances): X is zero-mean noise, so the sum over all frames
-of delta*x cancels to a small norm and fp32 accumulation over K = 32 000..64 000 terms shows --
-the same holds for the reference's cuBLAS sgemm.  The oracle runs in forked host processes
-(tests/helpers.oracle_parallel)."""
+<= 2e-8).  Gradients, relative Frobenius norm per tensor, TWO comparisons:
+ (a) against the oracle run with the DEVICE's ReLU / (0,maxAct) decisions imposed on its backward
+     pass: 1e-4 for every tensor (observed 2e-6): this is the arithmetic-quality bar;
+ (b) against the plain oracle: 3e-4, except the input-layer weight gradient dW1 = delta_1 . X^T
+     at 3e-3 (observed 6e-4 at T=1000, 1.2e-3 at T=2000).  test_cfg4_input_layer_gradient_error_
+     decomposed shows where (b)'s dW1 figure comes from: of 21.9 M gated units of a T=2000
+     utterance TWO sit within 6e-7 layer-sigmas of their kink and land on the other side in
+     float32; the delta of such a unit is present in one implementation and absent in the other.
+     X is zero-mean noise, so ||dW1|| is a random-walk norm and the two stray deltas are 7e-4 of
+     it, whereas the other tensors' norms carry a coherent part.  The dW1 contraction itself is
+     exact to 2e-7 on the device's own operands.  (The reference's cudamat-vs-rnnetcpu check,
+     debug-utils/checkgrads.py:20-40, has the same property.)
+The oracle runs in forked host processes (tests/helpers.oracle_parallel)."""
 import numpy as np
 import pytest
 
 from tests.helpers import oracle_parallel
 from tests.test_gpu_brnn import make_net, rel
 
-TOL = {"W1": 3e-3}          # every other tensor: TOL_DEFAULT
+TOL = {"W1": 3e-3}          # (b) plain oracle; every other tensor: TOL_DEFAULT
 TOL_DEFAULT = 3e-4
+TOL_MASKED = 1e-4           # (a) oracle with the device's gate decisions: every tensor
+
+
+def device_masks(net, NL, TL, H, B, T):
+    """i -> masks dict of utterance i for oracle.brnn.cost_and_grad, read back from the engine's
+    activation matrices of the LAST call (equal-length minibatch of B utterances: packed row of
+    frame t, utterance b is t*B + b)"""
+    acts = {i: net.debugBuffer(i)[:, :H].reshape(T, B, H) > 0.0 for i in range(1, NL + 1) if i != TL}
+    hF = net.debugBuffer(100)[:, :H].reshape(T, B, H)
+    hB = net.debugBuffer(101)[:, :H].reshape(T, B, H)
+    mF = (hF > 0.0) & (hF < 20.0)
+    mB = (hB > 0.0) & (hB < 20.0)
+
+    def masks_of(b):
+        return {"relu": {i: a[:, b, :].T for i, a in acts.items()}, "F": mF[:, b, :].T, "B": mB[:, b, :].T}
+    return masks_of
 
 
 def within_tol(worst):
@@ -80,6 +103,7 @@ def test_cfg3_minibatch32_vs_oracle(mods):
     costs, _, skips = net.costAndGradBatch(datas, labs)
     got = tensors(net, NL)
     assert not skips.any()
+    masks_of = device_masks(net, NL, TL, H, B, T)
     c_ref, g_ref, s_ref = oracle_parallel(params, datas, labs, TL)
     assert not s_ref.any()
     np.testing.assert_allclose(costs, c_ref, rtol=1e-4)
@@ -88,6 +112,14 @@ def test_cfg3_minibatch32_vs_oracle(mods):
     worst = {k: rel(got[k], want[k]) for k in want}
     print("cfg3 B=32 gradient rel-norm errors:", {k: "%.1e" % v for k, v in worst.items()})
     assert within_tol(worst), worst
+    # (a) the arithmetic-quality bar: the oracle's backward pass with the device's gate decisions
+    _, g_m, _ = oracle_parallel(params, datas, labs, TL, masks_of=masks_of)
+    del masks_of
+    want_m = oracle_tensors(g_m, NL)
+    worst_m = {k: rel(got[k], want_m[k]) for k in want_m}
+    print("cfg3 B=32 gradient rel-norm errors, oracle with the device's gates:",
+          {k: "%.1e" % v for k, v in worst_m.items()})
+    assert all(v < TOL_MASKED for v in worst_m.values()), worst_m
     # the same workload with the contractions on the bfloat16 matrix cores (three-term split, fp32-
     # accurate: NNet(..., gemm="bf16x3")) -- same oracle, same tolerances
     net3 = make_net(brnnet, (D, A, H, NL, TL, T), params, maxUtts=B, maxBatch=T, gemm="bf16x3")
@@ -240,7 +272,7 @@ def test_cfg4_input_layer_gradient_error_decomposed(mods):
           one side and absent on the other.  The flips are counted, every flipped unit is shown
           to sit on the kink (|pre-activation| tiny against the layer's scale), and
       (3) with the DEVICE's masks imposed on the oracle's backward pass every tensor, dW1
-          included, agrees to 3e-4: what separates the two implementations is the placement of
+          included, agrees to 1e-4: what separates the two implementations is the placement of
           tied units, not arithmetic quality (the reference's cudamat-vs-rnnetcpu comparison,
           debug-utils/checkgrads.py:20-40, has the same property)."""
     brnnet, obrnn, torch = mods
@@ -297,5 +329,5 @@ def test_cfg4_input_layer_gradient_error_decomposed(mods):
              worst_m["W1"], max(v for k, v in worst_m.items() if k != "W1")))
     assert e_gemm < 2e-5, e_gemm
     assert sum(flips.values()) <= 1e-4 * n_units and worst_tie < 1e-4, (flips, worst_tie)
-    assert all(v < TOL_DEFAULT for v in worst_m.values()), worst_m
+    assert all(v < TOL_MASKED for v in worst_m.values()), worst_m
     assert within_tol(worst), worst
