@@ -207,7 +207,10 @@ int sctc_brnn_cost_and_grad_async(sctc_brnn_t h, const sctc_minibatch* mb, int32
  * right after the gradient of parameter tensor `index` is final (a weight tensor's event covers
  * its bias; NULL for bias indices), and hipStreamWaitEvent for a caller that only holds raw
  * stream pointers -- a side stream waits for tensor i's event and starts its all-reduce while
- * the backward pass continues. */
+ * the backward pass continues.  The weight gradients of the layers above the temporal layer
+ * are final before the BPTT recurrence starts; their events are recorded only after it has retired, so that no
+ * collective kernel occupies compute units while the persistent BPTT grid (which needs all of
+ * its workgroups resident at once) is being placed. */
 void* sctc_brnn_grad_event(sctc_brnn_t h, int32_t index);
 int sctc_stream_wait_event(void* stream, void* event);
 /* synchronises `stream` and reports a failure of the asynchronous work queued on it:

@@ -682,7 +682,14 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             gemm_plan_splits(g.M, g.N, g.K, &splits, g.prec);
             g.splits = splits;
             SCTC_TRY(launch_gemm_f32(g, s));
-            SCTC_HIP_TRY(hipEventRecord(h->grad_ev[weight_index(h, i)], s));
+            // The weight gradients of the layers above the temporal layer (loop indices i >= TL: W_{TL+1}
+            // .. W_{NL+1}) finish BEFORE the BPTT recurrence starts.  A collective
+            // started on their event would hold compute units while the persistent BPTT grid is being
+            // placed (all of its workgroups must be resident at once; two-chain kernel: every register
+            // of 228 CUs): their events are recorded after BPTT has retired instead (below), so a
+            // data-parallel caller's all-reduces only ever overlap the time-batched GEMMs.
+            if (!(h->TL > 0 && i >= h->TL))
+                SCTC_HIP_TRY(hipEventRecord(h->grad_ev[weight_index(h, i)], s));
         }
         if (i == 0) break;
         pt.begin(SCTC_PHASE_BWD_GEMM);
@@ -748,6 +755,8 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             r.prec16 = h->cfg.operand_dtype == SCTC_F16;
             r.T_host = h->Ts.data();
             SCTC_TRY(launch_recurrent(r, s, &h->rec_path[1]));
+            for (int l = h->NL; l >= h->TL; --l)     // the held-back events of the layers above (see there)
+                SCTC_HIP_TRY(hipEventRecord(h->grad_ev[weight_index(h, l)], s));
             pt.begin(SCTC_PHASE_BWD_GEMM);
             if (h16) {   // A operands of the recurrent weight gradient
                 SCTC_TRY(launch_cvt16(h->dF, nullptr, h->dF16b, N * LD(h->Hp), s));

@@ -22,8 +22,12 @@
 // s' order and read back reversed by ctc_grad.
 //
 // Scaling: the reference renormalises every frame by c_t = sum over the band
-// (ctc_fast.pyx:70-76).  We multiply by r = fl(1/c) at the rescale points (see the lattice
-// kernel) and account llForward -= log(r) in float64, exact for whatever r was applied.
+// (ctc_fast.pyx:70-76).  We multiply by r ~ 1/c at the rescale points (see the lattice
+// kernel) and account llForward -= log(r) in float64, exact for whatever r was applied:
+// r is v_rcp_f64 + two Newton steps (half the dependent operations of the IEEE division
+// sequence, which sat on every frame's critical path), and the applied factors are not
+// tracked in registers but stored into the one lattice column no state ever occupies
+// (2U+1 is odd, the row stride even) and summed up after the last frame.
 #include "common.h"
 #include "ctc_kernels.h"
 #include "xlane.h"
@@ -251,19 +255,37 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
         }
         return (R)out;
     };
-    auto store_row = [&](int tau, const R (&v)[K]) {
+    // A row is stored together with the factor it was scaled with: L = 2U+1 is odd and the row
+    // stride LP even, so column LP-1 (last register of the last lane, always a zero state) is free.
+    // Keeping the factors in registers instead -- one per lane, folded 64 at a time -- cost a lane
+    // compare, a 64-bit select and a branch per frame: 166 of a frame's ~600 cycles (s_memtime).
+    const bool last_lane = gl == 64 * W - 1;
+    auto store_row = [&](int tau, const R (&v)[K], R factor) {
 #ifdef SCTC_CTC_NOSTORE
         if (tau != 0x7fffffff) return;
 #endif
         R* row = lat + (int64_t)tau * LP + (int64_t)K * gl;
+        const R vlast = last_lane ? factor : v[K - 1];
         if constexpr (K % 4 == 0) {
             typename Vec<R>::v4* dst = reinterpret_cast<typename Vec<R>::v4*>(row);
 #pragma unroll
-            for (int j = 0; j < K; j += 4) dst[j / 4] = {v[j], v[j + 1], v[j + 2], v[j + 3]};
+            for (int j = 0; j < K; j += 4)
+                dst[j / 4] = {v[j], v[j + 1], v[j + 2], j + 3 == K - 1 ? vlast : v[j + 3]};
         } else {
 #pragma unroll
-            for (int j = 0; j < K; ++j) row[j] = v[j];
+            for (int j = 0; j < K; ++j) row[j] = j == K - 1 ? vlast : v[j];
         }
+    };
+    // 1/c for the row scaling: hardware estimate + two Newton-Raphson steps (the reciprocal part of
+    // the IEEE division sequence without its scaling / fix-up tail; <= 1 ulp).  Which double is
+    // applied does not matter for parity: llForward takes the log of exactly this value, and the
+    // per-frame factors cancel in the gradient (ctc_fast.pyx:138-145).
+    auto recip = [&](R c) -> R {
+        R x = __builtin_amdgcn_rcp(c);
+        R e = fma(-c, x, (R)1);
+        x = fma(x, e, x);
+        e = fma(-c, x, (R)1);
+        return fma(x, e, x);
     };
 
     // workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the
@@ -312,10 +334,8 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
 #pragma unroll
     for (int j = 0; j < K; ++j) a[j] = (R)0;
 
-    double ll = 0.0;   // per-lane partial of llForward (float64 like the reference)
-    R rslot = (R)1;    // applied scale factors are parked one per lane and folded 64 at a time
-    int nscaled = 0;
     int skip = 0;
+    int n_rows = T;    // rows stored with their factor: all of them, or those before the frame that skipped
     R rprev = (R)1;    // factor applied to the previous frame's row (uniform)
     // T < U: the band [start,end) is empty at every frame t >= 1 (L >= 2T+2 does not depend
     // on t): the reference divides nothing, takes log(0) = -inf and returns cost +inf with
@@ -333,22 +353,21 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
         const R c = block_sum(a[0] + a[1], a[K - 1], 0);
         if (c == (R)0) {
             skip = 1;  // ZeroDivisionError at :45
+            n_rows = 0;
         } else {
-            const R r = (R)1 / c;
+            const R r = recip(c);
             a[0] *= r;
             a[1] *= r;
-            if (lane == 0) rslot = r;
-            nscaled = 1;
             rprev = r;
         }
-        store_row(0, a);
+        store_row(0, a, rprev);
     }
 
     if (!skip && empty_band) {
         R z[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) z[j] = (R)0;
-        for (int tau = 1; tau < T; ++tau) store_row(tau, z);
+        for (int tau = 1; tau < T; ++tau) store_row(tau, z, (R)1);
     } else if (!skip && T > 1) {
         static_assert(PF <= 64, "one lane per frame of a block");
         int rbv = block_rows(1);
@@ -408,17 +427,12 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
                             const R c = block_sum(loc, n[K - 1], tau);
                             if (c == (R)0) {
                                 skip = 1;
+                                n_rows = tau;
                             } else {
-                                const R r = (R)1 / c;
+                                const R r = recip(c);
 #pragma unroll
                                 for (int j = 0; j < K; ++j) a[j] = n[j] * r;
                                 rprev = r;
-                                if (lane == (nscaled & 63)) rslot = r;
-                                ++nscaled;
-                                if ((nscaled & 63) == 0) {
-                                    ll -= log((double)rslot);
-                                    rslot = (R)1;
-                                }
                             }
                         } else {
                             publish(n[K - 1], tau);
@@ -426,7 +440,7 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
 #pragma unroll
                             for (int j = 0; j < K; ++j) a[j] = n[j];
                         }
-                        if (!skip) store_row(tau, a);
+                        if (!skip) store_row(tau, a, rprev);
                     }
                 }
             } else {
@@ -466,17 +480,12 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
                         const R c = block_sum(loc, n[K - 1], tau);
                         if (c == (R)0) {
                             skip = 1;  // ZeroDivisionError at :75 (band is non-empty here)
+                            n_rows = tau;
                         } else {
-                            const R r = (R)1 / c;
+                            const R r = recip(c);
 #pragma unroll
                             for (int j = 0; j < K; ++j) a[j] = n[j] * r;
                             rprev = r;
-                            if (lane == (nscaled & 63)) rslot = r;
-                            ++nscaled;
-                            if ((nscaled & 63) == 0) {
-                                ll -= log((double)rslot);
-                                rslot = (R)1;
-                            }
                         }
                     } else {
                         publish(n[K - 1], tau);
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
 #pragma unroll
                         for (int j = 0; j < K; ++j) a[j] = n[j];
                     }
-                    if (!skip) store_row(tau, a);
+                    if (!skip) store_row(tau, a, rprev);
                 }
             }
             }
@@ -494,13 +503,21 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
                 for (int q = 0; q < NA; ++q) ycur[i][q] = ynxt[i][q];
         }
     }
-    // factors still parked
-    ll -= log((double)rslot);
-    double total = wave_sum(ll);
-    if (gl == 0) {
-        if (empty_band && !skip) total = -INFINITY;  // math.log(0.0)
-        p.ll[2 * b + dir] = total;                   // llForward (dir 0) / llBackward (dir 1)
-        p.skip2[2 * b + dir] = skip;
+    // llForward = sum_t log c_t (ctc_fast.pyx:47,76) = - sum over the stored factors.  The wave that
+    // stored them reads them back (its own stores, drained first; the lines were never cached):
+    // lane l takes frames l, l+64, ... in ascending order -- the order the in-register scheme this
+    // replaces summed them in, so llForward is bit-identical to it.
+    if (wave == W - 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        double ll = 0.0;   // per-lane partial of llForward (float64 like the reference)
+        const R* fac = lat + (LP - 1);
+        for (int tau = lane; tau < n_rows; tau += 64) ll -= log((double)fac[(int64_t)tau * LP]);
+        double total = wave_sum(ll);
+        if (lane == 0) {
+            if (empty_band && !skip) total = -INFINITY;  // math.log(0.0)
+            p.ll[2 * b + dir] = total;                   // llForward (dir 0) / llBackward (dir 1)
+            p.skip2[2 * b + dir] = skip;
+        }
     }
 }
 

@@ -156,3 +156,29 @@ def test_bench_two_ranks(backend):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["frames_per_step"] == 2 * 6 * 1000
     assert out["cost_check"]["rel_err"] < 1e-4
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_overlapped_allreduce_equals_flat_two_ranks(backend):
+    """the per-layer bucketed all-reduce queued behind the engine's gradient events
+    (dist_sgd.allreduce_overlapped) gives, bit for bit, what one flat all-reduce of the same local
+    gradients gives -- 2 ranks with different utterances, 3 steps (tests/gpu_dist_equiv.py).
+    gloo: both ranks on the one GPU of the box (the library's shared-device mode makes their
+    persistent launches take turns); nccl (RCCL): wherever two devices are visible."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank (%d visible)" % torch.cuda.device_count())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCTC_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29551" if backend == "gloo" else "29552",
+           os.path.join(root, "tests", "gpu_dist_equiv.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["ok"] and out["world"] == 2 and out["buckets"] == 6
+    if backend == "gloo":
+        assert out["shared_mode"] == 1        # LOCAL_WORLD_SIZE 2 > 1 visible device

@@ -176,3 +176,65 @@ def test_two_processes_hammer_one_gpu(tmp_path, mode):
                   % (o["tag"], o["retries"], o["path"], o["shared_mode"], same, steps, o["seconds"]))
             if o["retries"] == 0:
                 assert o["digests"] == solo["digests"]
+
+
+def test_collective_stand_in_during_backward(mods):
+    """Row (e) without an 8-GPU node: what a collective on the side stream does to the backward
+    pass.  The engine records the gradient events of the layers above the temporal layer only
+    AFTER the BPTT recurrence has retired, so a collective started on them (dist_sgd.
+    allreduce_overlapped) never holds compute units while the 456-workgroup persistent BPTT grid
+    is being placed.  Stand-in for RCCL: 32 workgroups (one per channel) that hold their CUs for
+    1.5 ms per bucket, launched on a side stream behind each bucket's event, cfg-3 layer sizes,
+    minibatch 32.  Must not time out, must not change a bit, and its cost is reported."""
+    import ctypes
+    import time
+    _sctc, brnnet, obrnn, torch = mods
+    from tools.diag import sctc_diag
+    D, A, H, NL, TL, T, B = 64, 33, 1824, 5, 3, 200, 32
+    np.random.seed(9)
+    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B)
+    net.initParams()
+    rs = np.random.RandomState(9)
+    datas = [rs.randn(D, T).astype(np.float32) for _ in range(B)]
+    labs = [rs.randint(1, A, size=T // 10).astype(np.int32) for _ in range(B)]
+    feats = net._stage(datas)
+    Tb = [T] * B
+    L, D_ = _sctc.lib(), sctc_diag.lib()
+    side = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+
+    def step(with_side):
+        net.costAndGradBatchAsync(None, labs, feats_dev=feats, T_b=Tb)
+        if with_side:
+            with torch.cuda.stream(side):
+                for ev, start, end in net.gradBuckets():
+                    _sctc.check(L.sctc_stream_wait_event(side.cuda_stream, ev), "wait")
+                    assert D_.sctc_diag_spin(ctypes.c_void_p(side.cuda_stream), 32, 1500) == 0
+            cur.wait_stream(side)
+        net.checkAsync()
+
+    def timed(with_side, n=6):
+        step(with_side)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(with_side)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    step(False)
+    g0 = net.grad.flat.clone()
+    base = timed(False)
+    with_side = timed(True)
+    assert torch.equal(net.grad.flat, g0)
+    assert net.recurrentPath() == (1, 1, 0)
+    base2 = timed(False)
+    print("collective stand-in (8 buckets x 32 workgroups x 1.5 ms on a side stream): %.2f ms per step "
+          "against %.2f / %.2f ms without (+%.1f %%)" % (with_side, base, base2, 100 * (with_side / min(base, base2) - 1)))
+    d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "test_notes.txt"), "a") as f:
+            f.write("collective stand-in: %.2f ms per step with, %.2f / %.2f without\n" % (with_side, base, base2))
+    # the stand-in occupies 32 of 256 CUs for 12 ms of a ~12 ms step: a generous bound on what is
+    # left to chance (placement of the spinning workgroups), the measured figure goes to DESIGN.md
+    assert with_side < 1.5 * min(base, base2)

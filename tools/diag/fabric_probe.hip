@@ -272,3 +272,28 @@ extern "C" int sctc_probe_mfma(float* results_host, int32_t n_results, void* str
     if (e != hipSuccess) return set_error(SCTC_ERR_HIP, "probe_mfma: %s", hipGetErrorString(e));
     return SCTC_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// sctc_diag_spin: n_wgs workgroups of 256 threads that do nothing but hold their compute units
+// for `microseconds` -- the stand-in for a collective kernel (RCCL: one workgroup per channel)
+// running on a side stream next to the backward pass (tests/test_gpu_shared.py).
+namespace sctc {
+__global__ __launch_bounds__(256) void spin_kernel(unsigned long long ticks, unsigned* sink)
+{
+    const unsigned long long t0 = wall_clock64();
+    unsigned n = 0;
+    while (wall_clock64() - t0 < ticks) { __builtin_amdgcn_s_sleep(8); ++n; }
+    if (sink && n == 0xffffffffu) *sink = n;
+}
+}  // namespace sctc
+
+extern "C" int sctc_diag_spin(void* stream, int32_t n_wgs, int32_t microseconds)
+{
+    using namespace sctc;
+    SCTC_CHECK_ARG(n_wgs >= 1 && n_wgs <= 4096 && microseconds >= 0 && microseconds <= 1000000,
+                   "diag_spin: bad argument");
+    hipLaunchKernelGGL(spin_kernel, dim3(n_wgs), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned long long)microseconds * 100ull, (unsigned*)nullptr);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}

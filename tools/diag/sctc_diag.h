@@ -25,6 +25,10 @@ int sctc_probe_fabric(float* results_host, int32_t n_results, void* stream);
  * then the same two with fresh random operands per MFMA group */
 int sctc_probe_mfma(float* results_host, int32_t n_results, void* stream);
 
+/* n_wgs workgroups of 256 threads that hold their compute units for `microseconds`: the stand-in
+ * for a collective kernel on a side stream (one workgroup per channel, like RCCL) */
+int sctc_diag_spin(void* stream, int32_t n_wgs, int32_t microseconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,5 +20,6 @@ def lib():
         L.sctc_selftest.argtypes = [ctypes.c_void_p]
         L.sctc_probe_fabric.argtypes = [f32p, ctypes.c_int32, ctypes.c_void_p]
         L.sctc_probe_mfma.argtypes = [f32p, ctypes.c_int32, ctypes.c_void_p]
+        L.sctc_diag_spin.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
         _lib = L
     return _lib
