@@ -477,16 +477,27 @@ def side_measurements(out, net, feats, labels, Ts, rs, torch, B, T, D):
     out["ragged"] = {"value": sum(Tr) / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
                      "frames_per_step": sum(Tr),
                      "note": "T_b ~ U[T/2, T] sorted descending, U_b = T_b/10, same net, HBM-resident"}
-    # north_star "one utterance per stream": the recurrence keeps W stationary on ALL compute units
-    # for a whole pass, so two such launches cannot be co-resident -- utterances on separate
-    # streams serialise, and the stream variant is exactly this: one utterance per call
+    # the reference's mode: minibatch 1, one call per utterance
     n1 = 4
     dt = timed(lambda: [net.costAndGradBatch(None, [labels[i]], feats_dev=feats[i * T:(i + 1) * T], T_b=[T])
                         for i in range(n1)], 2)
     out["one_utterance_per_call"] = {
         "value": n1 * T / dt, "unit": "frames/s", "ms_per_utterance": dt * 1e3 / n1,
-        "note": "the reference's mode (minibatch 1) and what one-utterance-per-stream degenerates to: "
-                "persistent weight-stationary launches of different streams cannot share the device"}
+        "note": "the reference's mode (minibatch 1), one synchronous call per utterance"}
+    # north_star "a minibatch of utterances shards one-utterance-per-stream on one GPU": minibatch-1
+    # steps on n HIP streams, their kernels overlapping on the device (NNet.costAndGradStreams; two
+    # 228-workgroup grids of the small-batch persistent recurrence fit the part side by side)
+    n8 = min(8, B)
+    per = {}
+    for ns in (1, 2, 3):
+        dt = timed(lambda: net.costAndGradStreams(None, labels[:n8], n_streams=ns, feats_dev=feats[:n8 * T],
+                                                  T_b=[T] * n8), 2)
+        per[ns] = n8 * T / dt
+    out["one_utterance_per_stream"] = {
+        "value": per[2], "unit": "frames/s", "streams": 2, "utterances": n8,
+        "by_streams": {str(k): v for k, v in per.items()},
+        "note": "every utterance its own minibatch-1 costAndGrad on one of n HIP streams, gradients "
+                "summed; the packed time-major minibatch (`value`) is the faster way to use the part"}
 
 
 def ctc_saturation(out, torch, A, T, U):

@@ -1430,7 +1430,10 @@ static int launch_recurrent_one(const RecArgs& a, const LaunchCtx& cx)
         }
         if (sk) {
             const size_t smem = sizeof(float) * 2 * (s4 ? 4 : 8) * a.Hp;
-            SCTC_TRY(launch_persistent(sk, 2 * nwg, smem, 1, (size_t)2 * a.n_xrows * a.Hp * sizeof(float), a, cx, &done));
+            // <= 239 VGPRs and 58 KiB of LDS (1..4 utterances at H = 1824): TWO of these workgroups fit
+            // a CU, so the grids of two streams (one utterance per stream) can be co-resident -- the
+            // in-process gate counts this launch as half the device
+            SCTC_TRY(launch_persistent(sk, 2 * nwg, smem, 2, (size_t)2 * a.n_xrows * a.Hp * sizeof(float), a, cx, &done));
             if (done) return SCTC_OK;
         }
     }

@@ -266,6 +266,96 @@ class NNet:
         self._async_keep = (feats_dev, keep)      # host label arrays / features outlive the launches
         return cost_dev, skip_dev
 
+    # ------------------------------------------------------------------ one utterance per stream
+
+    def _lanes_for(self, n_streams):
+        """n_streams minibatch-1 engines over the SAME parameter buffer, each with its own workspace,
+        HIP stream and (lane 0 excepted: it writes the model's gradient stack directly) gradient
+        buffer"""
+        torch = _sctc.require_gpu()
+        lanes = getattr(self, "_lanes", None)
+        if lanes is not None and len(lanes) == n_streams:
+            return lanes
+        L = _sctc.lib()
+        cfg = _sctc.BrnnConfig(self.inputDim, self.outputDim, self.layerSize, self.numLayers,
+                               self.temporalLayer, int(self.maxBatch), 1,
+                               float(self.maxAct) if self.maxAct else 0.0, float(self.reg), 1,
+                               self._cfg.operand_dtype)
+        sizes = _sctc.BrnnSizes()
+        _sctc.check(L.sctc_brnn_query(ctypes.byref(cfg), ctypes.byref(sizes)), "NNet lanes")
+        lanes = []
+        for k in range(n_streams):
+            grads = self._grads if k == 0 else torch.zeros_like(self._grads)
+            ws = torch.empty(sizes.workspace_bytes, dtype=torch.uint8, device="cuda")
+            h = ctypes.c_void_p()
+            _sctc.check(L.sctc_brnn_create(ctypes.byref(cfg), self._params.data_ptr(), grads.data_ptr(),
+                                           ws.data_ptr(), sizes.workspace_bytes, ctypes.byref(h)), "NNet lanes")
+            lanes.append({"h": h, "grads": grads, "ws": ws, "stream": torch.cuda.Stream(), "cfg": cfg})
+        self._lanes = lanes
+        return lanes
+
+    def costAndGradStreams(self, data_list, labels_list, n_streams=2, feats_dev=None, T_b=None,
+                           reg_in_grad=True):
+        """north_star's "a minibatch of utterances shards one-utterance-per-stream on one GPU": every
+        utterance is its own minibatch-1 costAndGrad -- the reference's mode, sgd.py:70-95 -- queued
+        on one of `n_streams` HIP streams without a host sync; the streams' kernels overlap on the
+        device (two 228-workgroup grids of the small-batch persistent recurrence fit the part side by
+        side; the library's in-process gate admits no more than fit, recurrent.hip).  Returns what
+        costAndGradBatch returns: (costs float64[B], grad stack = SUM over the non-skipped
+        utterances, skips bool[B]).  Measured slower than the packed minibatch (bench.py
+        `one_utterance_per_stream`); kept because it is the variant the north star names."""
+        torch = _sctc.require_gpu()
+        if self._h is None:
+            raise RuntimeError("initParams() / fromFile() first")
+        if not self.train:
+            raise RuntimeError("costAndGradStreams needs a train=True model")
+        if feats_dev is None:
+            T_b = [np.asarray(d).shape[1] for d in data_list]
+            feats_dev = self._stage(data_list)
+        for T in T_b:
+            self.setViews(T)
+        B = len(T_b)
+        L = _sctc.lib()
+        lanes = self._lanes_for(max(1, min(int(n_streams), B)))
+        cur = torch.cuda.current_stream()
+        cost_dev = torch.zeros(B, dtype=torch.float64, device="cuda")
+        skip_dev = torch.zeros(B, dtype=torch.int32, device="cuda")
+        keep = []
+        used = [False] * len(lanes)
+        for ln in lanes:
+            ln["stream"].wait_stream(cur)              # features / parameters are produced on `cur`
+        off = 0
+        for i in range(B):
+            k = i % len(lanes)
+            ln = lanes[k]
+            mb, kp = self._minibatch(feats_dev[off:off + T_b[i]], [T_b[i]], [labels_list[i]])
+            keep.append((mb, kp))
+            off += T_b[i]
+            flags = (_sctc.FLAG_ACCUMULATE if used[k] else 0) | \
+                    (0 if (reg_in_grad and i == 0) else _sctc.FLAG_NO_REG_GRAD)
+            if used[k]:
+                # an engine's host-side plan (row tables, CTC descriptors) is reused by its next call:
+                # the lane's previous utterance must have consumed it.  The OTHER lanes keep the device
+                # busy meanwhile.
+                _sctc.check(L.sctc_brnn_check(ln["h"], ctypes.c_void_p(ln["stream"].cuda_stream)), "costAndGrad")
+            used[k] = True
+            rc = L.sctc_brnn_cost_and_grad_async(ln["h"], ctypes.byref(mb), flags,
+                                                 cost_dev.data_ptr() + 8 * i, skip_dev.data_ptr() + 4 * i,
+                                                 ctypes.c_void_p(ln["stream"].cuda_stream))
+            _sctc.check(rc, "costAndGrad")
+        for k, ln in enumerate(lanes):
+            _sctc.check(L.sctc_brnn_check(ln["h"], ctypes.c_void_p(ln["stream"].cuda_stream)), "costAndGrad")
+            cur.wait_stream(ln["stream"])
+            if k > 0 and used[k]:                      # lane 0 wrote the model's gradient stack itself
+                _sctc.check(L.sctc_axpy(self._grads.data_ptr(), ln["grads"].data_ptr(), 1.0,
+                                        self._grads.numel(), _sctc.current_stream_ptr()), "costAndGrad")
+        if self.reg > 0:
+            self.regcost = float(self.regCostDev().item())
+        cost = cost_dev.cpu().numpy()
+        skip = skip_dev.cpu().numpy().astype(bool)
+        del keep
+        return cost, self.grad, skip
+
     def checkAsync(self):
         """synchronises the current stream; raises if a persistent kernel of the queued step timed out"""
         _sctc.check(_sctc.lib().sctc_brnn_check(self._h, _sctc.current_stream_ptr()), "costAndGrad")
@@ -427,6 +517,9 @@ class NNet:
 
     def __del__(self):
         try:
+            for ln in getattr(self, "_lanes", None) or []:
+                _sctc.lib().sctc_brnn_destroy(ln["h"])
+            self._lanes = None
             if self._h is not None:
                 _sctc.lib().sctc_brnn_destroy(self._h)
                 self._h = None

@@ -238,3 +238,59 @@ def test_collective_stand_in_during_backward(mods):
     # the stand-in occupies 32 of 256 CUs for 12 ms of a ~12 ms step: a generous bound on what is
     # left to chance (placement of the spinning workgroups), the measured figure goes to DESIGN.md
     assert with_side < 1.5 * min(base, base2)
+
+
+@pytest.mark.parametrize("n_streams", [1, 2, 3])
+def test_one_utterance_per_stream(mods, n_streams):
+    """north_star "a minibatch of utterances shards one-utterance-per-stream on one GPU"
+    (NNet.costAndGradStreams): every utterance is a minibatch-1 step on one of n HIP streams; costs,
+    skips and the summed gradient equal the packed minibatch's (costAndGradBatch) and the oracle's;
+    with three streams the in-process gate must make the third persistent grid wait (two 228-
+    workgroup grids of the small-batch kernel fit the part, three do not)."""
+    _, brnnet, obrnn, torch = mods
+    D, A, H, NL, TL = 24, 12, 512, 3, 2
+    rs = np.random.RandomState(40 + n_streams)
+    Ts = [int(t) for t in rs.randint(4, 30, size=7)]
+    params, datas, labs = _problem(obrnn, 17, D, A, H, NL, TL, Ts)
+    labs[3] = np.array([5] * (Ts[3] // 2 + 1), dtype=np.int32)      # infeasible repeats -> skip
+    with np.errstate(all="ignore"):
+        costs_ref, g_ref, skips_ref, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+    assert skips_ref[3] and skips_ref.sum() == 1
+    net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=len(Ts))
+    costs, _, skips = net.costAndGradStreams(datas, labs, n_streams=n_streams)
+    np.testing.assert_array_equal(skips, skips_ref)
+    np.testing.assert_allclose(costs[~skips_ref], costs_ref[~skips_ref], rtol=1e-4)
+    check_grads(net, g_ref, NL)
+    g_s = _all_grads(net, NL)
+    costs_b, _, skips_b = net.costAndGradBatch(datas, labs)
+    np.testing.assert_array_equal(skips_b, skips)
+    np.testing.assert_allclose(costs_b[~skips], costs[~skips], rtol=1e-5)
+    for a, b in zip(g_s, _all_grads(net, NL)):
+        assert rel(a, b) < 1e-4
+    # twice in a row: the lanes are reused, gradients start from zero again
+    net.costAndGradStreams(datas, labs, n_streams=n_streams)
+    for a, b in zip(g_s, _all_grads(net, NL)):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_one_utterance_per_stream_full_width(mods):
+    """the same at H = 1824 (the 228-workgroup small-batch grids of two streams side by side on the
+    256 CUs), against one utterance per call"""
+    _, brnnet, obrnn, torch = mods
+    D, A, H, NL, TL, T = 32, 33, 1824, 3, 2, 60
+    rs = np.random.RandomState(5)
+    np.random.seed(11)
+    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=4)
+    net.initParams()
+    datas = [rs.randn(D, T - 3 * b).astype(np.float32) for b in range(4)]
+    labs = [rs.randint(1, A, size=5).astype(np.int32) for _ in range(4)]
+    costs, _, skips = net.costAndGradStreams(datas, labs, n_streams=2)
+    g_s = _all_grads(net, NL)
+    tot = None
+    for d, l in zip(datas, labs):
+        c, _, s = net.costAndGrad(d, l)
+        g = _all_grads(net, NL)
+        tot = g if tot is None else [a + b for a, b in zip(tot, g)]
+    assert not skips.any()
+    for a, b in zip(g_s, tot):
+        assert rel(a, b) < 1e-5
