@@ -330,10 +330,29 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
         return prev;
     };
 
+    // sum of a lane's K new states as a balanced tree (log2 K dependent additions instead of K-1)
+    auto local_sum = [&](const R (&n)[K]) -> R {
+        R t[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) t[j] = n[j];
+#pragma unroll
+        for (int w = 1; w < K; w *= 2)
+#pragma unroll
+            for (int j = 0; j + w < K; j += 2 * w) t[j] += t[j + w];
+        return t[0];
+    };
+
     R a[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) a[j] = (R)0;
 
+    // A zero band sum (the reference's ZeroDivisionError, ctc_fast.pyx:75) is not branched on frame by
+    // frame: the frame index is latched in a scalar, the recursion runs on (through NaNs, whose rows
+    // nobody reads) and the block of frames ends the pass.  A compare-and-branch per frame put a
+    // VALU -> SALU -> branch round trip on the recursion's dependency chain and cut the unrolled block
+    // into one basic block per frame.
+    constexpr int NO_BAD = 0x7fffffff;
+    int first_bad = NO_BAD;
     int skip = 0;
     int n_rows = T;    // rows stored with their factor: all of them, or those before the frame that skipped
     R rprev = (R)1;    // factor applied to the previous frame's row (uniform)
@@ -410,7 +429,6 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
 #pragma unroll
                     for (int i = 0; i < PF; ++i) {
                         const int tau = tb + i;
-                        if (skip) continue;
                         const R yb = ybv[i];
                         const R prev_last = shift_in(a, tau, rprev);
                         R n[K];
@@ -421,33 +439,26 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
                             n[2 * jj + 1] = fma(below, allowf[jj], a[2 * jj + 1] + a[2 * jj]) * ylv[i][jj];
                         }
                         if ((tau % RS) == 0) {
-                            R loc = n[0];
+                            const R c = block_sum(local_sum(n), n[K - 1], tau);
+                            first_bad = (c == (R)0 && first_bad == NO_BAD) ? tau : first_bad;
+                            const R r = recip(c);
 #pragma unroll
-                            for (int j = 1; j < K; ++j) loc += n[j];
-                            const R c = block_sum(loc, n[K - 1], tau);
-                            if (c == (R)0) {
-                                skip = 1;
-                                n_rows = tau;
-                            } else {
-                                const R r = recip(c);
-#pragma unroll
-                                for (int j = 0; j < K; ++j) a[j] = n[j] * r;
-                                rprev = r;
-                            }
+                            for (int j = 0; j < K; ++j) a[j] = n[j] * r;
+                            rprev = r;
                         } else {
                             publish(n[K - 1], tau);
                             rprev = (R)1;
 #pragma unroll
                             for (int j = 0; j < K; ++j) a[j] = n[j];
                         }
-                        if (!skip) store_row(tau, a, rprev);
+                        store_row(tau, a, rprev);
                     }
                 }
             } else {
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int tau = tb + i;
-                if (tau < T && !skip) {
+                if (tau < T) {
                     // lower band limit, ctc_fast.pyx:49-53 (identical for the reversed problem);
                     // states >= end are exactly zero by construction
                     const int rem = 2 * (T - tau);
@@ -474,28 +485,26 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
                     if ((tau % RS) == 0 || tau == T - 1) {
                         // rescale (every frame when RS == 1, like :70-76); the last frame always,
                         // so that llForward is complete
-                        R loc = n[0];
+                        const R c = block_sum(local_sum(n), n[K - 1], tau);
+                        // c == 0: ZeroDivisionError at :75 (the band is non-empty here)
+                        first_bad = (c == (R)0 && first_bad == NO_BAD) ? tau : first_bad;
+                        const R r = recip(c);
 #pragma unroll
-                        for (int j = 1; j < K; ++j) loc += n[j];
-                        const R c = block_sum(loc, n[K - 1], tau);
-                        if (c == (R)0) {
-                            skip = 1;  // ZeroDivisionError at :75 (band is non-empty here)
-                            n_rows = tau;
-                        } else {
-                            const R r = recip(c);
-#pragma unroll
-                            for (int j = 0; j < K; ++j) a[j] = n[j] * r;
-                            rprev = r;
-                        }
+                        for (int j = 0; j < K; ++j) a[j] = n[j] * r;
+                        rprev = r;
                     } else {
                         publish(n[K - 1], tau);
                         rprev = (R)1;
 #pragma unroll
                         for (int j = 0; j < K; ++j) a[j] = n[j];
                     }
-                    if (!skip) store_row(tau, a, rprev);
+                    store_row(tau, a, rprev);
                 }
             }
+            }
+            if (first_bad != NO_BAD) {
+                skip = 1;
+                n_rows = first_bad;
             }
 #pragma unroll
             for (int i = 0; i < PF; ++i)

@@ -184,8 +184,8 @@ def test_collective_stand_in_during_backward(mods):
     AFTER the BPTT recurrence has retired, so a collective started on them (dist_sgd.
     allreduce_overlapped) never holds compute units while the 456-workgroup persistent BPTT grid
     is being placed.  Stand-in for RCCL: 32 workgroups (one per channel) that hold their CUs for
-    1.5 ms per bucket, launched on a side stream behind each bucket's event, cfg-3 layer sizes,
-    minibatch 32.  Must not time out, must not change a bit, and its cost is reported."""
+    0.3 ms per bucket (a 13 MB bucket over 7 xGMI links), launched on a side stream behind each
+    bucket's event, cfg-3 layer sizes, minibatch 32.  Must not time out, must not change a bit, and its cost is reported."""
     import ctypes
     import time
     _sctc, brnnet, obrnn, torch = mods
@@ -209,7 +209,7 @@ def test_collective_stand_in_during_backward(mods):
             with torch.cuda.stream(side):
                 for ev, start, end in net.gradBuckets():
                     _sctc.check(L.sctc_stream_wait_event(side.cuda_stream, ev), "wait")
-                    assert D_.sctc_diag_spin(ctypes.c_void_p(side.cuda_stream), 32, 1500) == 0
+                    assert D_.sctc_diag_spin(ctypes.c_void_p(side.cuda_stream), 32, 300) == 0
             cur.wait_stream(side)
         net.checkAsync()
 
@@ -229,15 +229,16 @@ def test_collective_stand_in_during_backward(mods):
     assert torch.equal(net.grad.flat, g0)
     assert net.recurrentPath() == (1, 1, 0)
     base2 = timed(False)
-    print("collective stand-in (8 buckets x 32 workgroups x 1.5 ms on a side stream): %.2f ms per step "
+    print("collective stand-in (8 buckets x 32 workgroups x 0.3 ms on a side stream): %.2f ms per step "
           "against %.2f / %.2f ms without (+%.1f %%)" % (with_side, base, base2, 100 * (with_side / min(base, base2) - 1)))
     d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
     if os.path.isdir(d):
         with open(os.path.join(d, "test_notes.txt"), "a") as f:
             f.write("collective stand-in: %.2f ms per step with, %.2f / %.2f without\n" % (with_side, base, base2))
-    # the stand-in occupies 32 of 256 CUs for 12 ms of a ~12 ms step: a generous bound on what is
-    # left to chance (placement of the spinning workgroups), the measured figure goes to DESIGN.md
-    assert with_side < 1.5 * min(base, base2)
+    # 2.4 ms of side-stream occupancy (32 of 256 CUs) inside a ~9 ms step, all of it after BPTT: a
+    # generous bound on what is left to chance (placement of the spinning workgroups next to the
+    # GEMMs' blocks); the measured figure goes to DESIGN.md 7
+    assert with_side < 1.25 * min(base, base2)
 
 
 @pytest.mark.parametrize("n_streams", [1, 2, 3])
