@@ -496,7 +496,7 @@ def side_measurements(out, net, feats, labels, Ts, rs, torch, B, T, D):
     # 228-workgroup grids of the small-batch persistent recurrence fit the part side by side)
     n8 = min(8, B)
     per = {}
-    for ns in (1, 2, 3):
+    for ns in (1, 2, 3, 4):
         dt = timed(lambda: net.costAndGradStreams(None, labels[:n8], n_streams=ns, feats_dev=feats[:n8 * T],
                                                   T_b=[T] * n8), 2)
         per[ns] = n8 * T / dt

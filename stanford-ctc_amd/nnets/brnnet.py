@@ -269,12 +269,13 @@ class NNet:
     # ------------------------------------------------------------------ one utterance per stream
 
     def _lanes_for(self, n_streams):
-        """n_streams minibatch-1 engines over the SAME parameter buffer, each with its own workspace,
-        HIP stream and (lane 0 excepted: it writes the model's gradient stack directly) gradient
-        buffer"""
+        """2 x n_streams minibatch-1 engines over the SAME parameter buffer (two per HIP stream, used
+        alternately: an engine's host-side plan must not be rewritten while its previous utterance
+        is still queued), each with its own workspace and (lane 0 excepted: it writes the model's
+        gradient stack directly) gradient buffer"""
         torch = _sctc.require_gpu()
         lanes = getattr(self, "_lanes", None)
-        if lanes is not None and len(lanes) == n_streams:
+        if lanes is not None and len(lanes) == 2 * n_streams:
             return lanes
         L = _sctc.lib()
         cfg = _sctc.BrnnConfig(self.inputDim, self.outputDim, self.layerSize, self.numLayers,
@@ -284,13 +285,14 @@ class NNet:
         sizes = _sctc.BrnnSizes()
         _sctc.check(L.sctc_brnn_query(ctypes.byref(cfg), ctypes.byref(sizes)), "NNet lanes")
         lanes = []
-        for k in range(n_streams):
+        streams = [torch.cuda.Stream() for _ in range(n_streams)]
+        for k in range(2 * n_streams):
             grads = self._grads if k == 0 else torch.zeros_like(self._grads)
             ws = torch.empty(sizes.workspace_bytes, dtype=torch.uint8, device="cuda")
             h = ctypes.c_void_p()
             _sctc.check(L.sctc_brnn_create(ctypes.byref(cfg), self._params.data_ptr(), grads.data_ptr(),
                                            ws.data_ptr(), sizes.workspace_bytes, ctypes.byref(h)), "NNet lanes")
-            lanes.append({"h": h, "grads": grads, "ws": ws, "stream": torch.cuda.Stream(), "cfg": cfg})
+            lanes.append({"h": h, "grads": grads, "ws": ws, "stream": streams[k % n_streams], "cfg": cfg})
         self._lanes = lanes
         return lanes
 
@@ -322,7 +324,7 @@ class NNet:
         skip_dev = torch.zeros(B, dtype=torch.int32, device="cuda")
         keep = []
         used = [False] * len(lanes)
-        for ln in lanes:
+        for ln in lanes[:len(lanes) // 2]:
             ln["stream"].wait_stream(cur)              # features / parameters are produced on `cur`
         off = 0
         for i in range(B):
@@ -335,8 +337,7 @@ class NNet:
                     (0 if (reg_in_grad and i == 0) else _sctc.FLAG_NO_REG_GRAD)
             if used[k]:
                 # an engine's host-side plan (row tables, CTC descriptors) is reused by its next call:
-                # the lane's previous utterance must have consumed it.  The OTHER lanes keep the device
-                # busy meanwhile.
+                # the engine's previous utterance (two rounds ago on this stream) must have consumed it
                 _sctc.check(L.sctc_brnn_check(ln["h"], ctypes.c_void_p(ln["stream"].cuda_stream)), "costAndGrad")
             used[k] = True
             rc = L.sctc_brnn_cost_and_grad_async(ln["h"], ctypes.byref(mb), flags,

@@ -253,7 +253,7 @@ def test_one_utterance_per_stream(mods, n_streams):
     rs = np.random.RandomState(40 + n_streams)
     Ts = [int(t) for t in rs.randint(4, 30, size=7)]
     params, datas, labs = _problem(obrnn, 17, D, A, H, NL, TL, Ts)
-    labs[3] = np.array([5] * (Ts[3] // 2 + 1), dtype=np.int32)      # infeasible repeats -> skip
+    labs[3] = np.array([5] * (Ts[3] // 2 + 2), dtype=np.int32)      # U repeats need 2U-1 > T frames -> skip
     with np.errstate(all="ignore"):
         costs_ref, g_ref, skips_ref, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
     assert skips_ref[3] and skips_ref.sum() == 1
