@@ -62,17 +62,6 @@ struct sctc_brnn {
     float *Z, *hF, *hB;       // temporal layer: pre-activation, forward / backward states
     float *logits, *probs, *dlogits;
     float *dA, *dBuf, *dF, *dBk;  // deltas: ping-pong pair + recurrent pair
-    float* dC = nullptr;          // third delta buffer of the rotation (two-stream backward pass)
-    float* splitk_ws2 = nullptr;  // split-K partials of the delta-propagation GEMMs when the weight-
-                                  // gradient GEMMs run concurrently on the side stream
-    // Two-stream backward pass: the weight-gradient GEMM of a layer (side stream) runs next to its
-    // delta-propagation GEMM (caller's stream).  Both read the same delta, neither depends on the other
-    // (brnnet.py:196 vs :204); run back to back each of the eleven large launches drains to a partial
-    // last round of tiles (4750 tiles over 1024 block slots) before the next one starts.
-    hipStream_t side = nullptr;
-    hipEvent_t ev_delta = nullptr, ev_side = nullptr;
-    hipEvent_t ev_wdone[2] = {nullptr, nullptr};   // weight gradient of an even / odd layer finished (side stream)
-    int bwd_overlap = 1;          // env SCTC_BWD_OVERLAP (default 1); off while phase timers run
     // 16-bit shadow copies (operand_dtype = SCTC_F16 only; nullptr otherwise): f = float16 (forward
     // operands), b = bfloat16 (backward operands).  Written by the producer of the fp32 matrix.
     std::vector<uint16_t*> act16f, act16b;      // [NL + 1], shadows of act[i]
@@ -208,12 +197,11 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
     if (d.TL > 0) { Z = f(F * LD(d.Hp)); hF = f(F * LD(d.Hp)); hB = f(F * LD(d.Hp)); }
     float* logits = f(F * LD(d.Ap));
     float* probs = f(F * LD(d.Ap));
-    float *dlogits = nullptr, *dA = nullptr, *dBuf = nullptr, *dF = nullptr, *dBk = nullptr, *dC = nullptr;
+    float *dlogits = nullptr, *dA = nullptr, *dBuf = nullptr, *dF = nullptr, *dBk = nullptr;
     if (c->train) {
         dlogits = f(F * LD(d.Ap));
         dA = f(F * LD(d.Hp));
         dBuf = f(F * LD(d.Hp));
-        dC = f(F * LD(d.Hp));
         if (d.TL > 0) { dF = f(F * LD(d.Hp)); dBk = f(F * LD(d.Hp)); }
     }
     // 16-bit shadows
@@ -283,7 +271,6 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
     sk = std::max<int64_t>(sk, std::min<int64_t>((int64_t)2 * 1024 * 128 * 128,
                                                  (int64_t)64 * F * (std::max(d.Hp, d.Ap) + 1)));
     float* splitk_ws = sk ? f(sk) : nullptr;
-    float* splitk_ws2 = (sk && c->train) ? f(sk) : nullptr;
     float* xbuf = d.TL > 0 ? f((int64_t)recurrent_xbuf_floats(d.Hp, recurrent_xrows_bound(F, F))) : nullptr;
     unsigned* counters = ar.take<unsigned>(REC_COUNTER_WORDS);
     unsigned* rec_debug = ar.take<unsigned>(2 * REC_DEBUG_WORDS);
@@ -296,7 +283,7 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
     if (h && !ar.overflow) {
         h->X0 = X0; h->act = act; h->Z = Z; h->hF = hF; h->hB = hB;
         h->logits = logits; h->probs = probs; h->dlogits = dlogits;
-        h->dA = dA; h->dBuf = dBuf; h->dF = dF; h->dBk = dBk; h->dC = dC; h->splitk_ws2 = splitk_ws2;
+        h->dA = dA; h->dBuf = dBuf; h->dF = dF; h->dBk = dBk;
         h->d_rowbase = d_rowbase; h->d_nact = d_nact; h->d_Ts = d_Ts; h->d_src_row = d_src_row;
         h->d_idx_lo = d_idx_lo; h->d_idx_hi = d_idx_hi; h->d_perm = d_perm; h->d_xbase = d_xbase;
         h->ctc_ws = ctc_ws; h->ctc_ws_bytes = ctc_bytes;
@@ -639,16 +626,6 @@ __global__ void unpermute_results_kernel(const double* cost, const int32_t* skip
     }
 }
 
-static void maybe_split2(const sctc_brnn* h, GemmArgs& g, float* ws)
-{
-    int sp = 1;
-    const int64_t need = gemm_plan_splits(g.M, g.N, g.K, &sp, g.prec);
-    if (sp > 1 && ws && need <= h->splitk_floats) {
-        g.splits = sp;
-        g.splitk_ws = ws;
-    }
-}
-
 static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
 {
     const int64_t N = h->N;
@@ -656,19 +633,10 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
     const float reg = (flags & SCTC_FLAG_NO_REG_GRAD) ? 0.f : h->cfg.reg;
     const int bprec = bwd_prec(h->cfg.operand_dtype);             // SCTC_F16 -> backward: bfloat16 operands
     const bool h16 = h->cfg.operand_dtype == SCTC_F16;            // 16-bit shadow operands
-    // Two streams (struct sctc_brnn): weight-gradient GEMMs on `ws`, everything else on the caller's
-    // stream `s`.  Not with the 16-bit shadows (their ping-pong pair has no third buffer) and not while
-    // the phase timers run (they time the caller's stream).
-    const bool two = h->bwd_overlap && h->side && !h16 && !h->profiling;
-    hipStream_t ws = two ? h->side : s;
     const float* d_in = h->dlogits;
     const uint16_t* d_in16 = h->dlogits16;
     int d_in_ld = LD(h->Ap);
-    // delta buffers rotate: layer i reads d_in and writes d_out; with three buffers the weight-gradient
-    // GEMM of layer i (still reading d_in on the side stream) only has to be finished before the delta
-    // propagation of layer i-2 overwrites that buffer
-    float* bufs[3] = {h->dA, h->dBuf, h->dC};
-    const int nbuf = two ? 3 : 2;
+    float* bufs[2] = {h->dA, h->dBuf};
     uint16_t* bufs16[2] = {h->dA16, h->dBuf16};
     if (h16) {
         SCTC_TRY(launch_cvt16(h->dlogits, nullptr, h->dlogits16, N * LD(h->Ap), s));
@@ -678,19 +646,6 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             SCTC_TRY(launch_transpose_bf16(h->params + wl.offset, LD(h->Hp), h->WT16b[l], LD(outp), outp, h->Hp, s));
         }
     }
-    // the side stream starts behind everything queued so far (the previous call's join, the CTC gradient)
-    auto side_waits_for_main = [&]() -> int {
-        if (!two) return SCTC_OK;
-        SCTC_HIP_TRY(hipEventRecord(h->ev_delta, s));
-        SCTC_HIP_TRY(hipStreamWaitEvent(ws, h->ev_delta, 0));
-        return SCTC_OK;
-    };
-    auto main_waits_for_side = [&]() -> int {
-        if (!two) return SCTC_OK;
-        SCTC_HIP_TRY(hipEventRecord(h->ev_side, ws));
-        SCTC_HIP_TRY(hipStreamWaitEvent(s, h->ev_side, 0));
-        return SCTC_OK;
-    };
     int which = 0;
     for (int i = h->NL; i >= 0; --i) {          // brnnet.py:191-243
         pt.begin(SCTC_PHASE_BWD_GEMM);
@@ -698,8 +653,6 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
         const int inp = i == 0 ? h->Dp : h->Hp;
         const int outp = i == h->NL ? h->Ap : h->Hp;
         const float* W = h->params + wi.offset;
-        // d_in is final on the caller's stream here: the side stream may read it
-        SCTC_TRY(side_waits_for_main());
         // dW = deltasIn . hActs[i]^T (+ reg*W), brnnet.py:196-198
         {
             GemmArgs g = gemm_defaults();
@@ -728,7 +681,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             int splits = 1;
             gemm_plan_splits(g.M, g.N, g.K, &splits, g.prec);
             g.splits = splits;
-            SCTC_TRY(launch_gemm_f32(g, ws));
+            SCTC_TRY(launch_gemm_f32(g, s));
             // The weight gradients of the layers above the temporal layer (loop indices i >= TL: W_{TL+1}
             // .. W_{NL+1}) finish BEFORE the BPTT recurrence starts.  A collective
             // started on their event would hold compute units while the persistent BPTT grid is being
@@ -736,7 +689,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             // of 228 CUs): their events are recorded after BPTT has retired instead (below), so a
             // data-parallel caller's all-reduces only ever overlap the time-batched GEMMs.
             if (!(h->TL > 0 && i >= h->TL))
-                SCTC_HIP_TRY(hipEventRecord(h->grad_ev[weight_index(h, i)], ws));
+                SCTC_HIP_TRY(hipEventRecord(h->grad_ev[weight_index(h, i)], s));
         }
         if (i == 0) break;
         pt.begin(SCTC_PHASE_BWD_GEMM);
@@ -763,16 +716,13 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
                 g.B = reinterpret_cast<const float*>(h->WT16b[i]);   // B(k = out, n = in) = W^T[in][out]
                 g.ldb = LD(outp);
                 g.b_kcontig = 1;
-                g.C16b = bufs16[which & 1];
+                g.C16b = bufs16[which];
                 g.ldc16 = LD(inp);
             }
-            maybe_split2(h, g, two ? h->splitk_ws2 : h->splitk_ws);
+            maybe_split(h, g);
             SCTC_TRY(launch_gemm_f32(g, s));
         }
         if (i == h->TL) {
-            // the persistent BPTT grid gets the device to itself: whatever the side stream still has
-            // in flight (the weight gradients of the layers above) is joined first
-            SCTC_TRY(main_waits_for_side());
             pt.begin(SCTC_PHASE_BWD_REC);
             RecArgs r;
             memset(&r, 0, sizeof(r));
@@ -814,7 +764,6 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             }
             // dwtf = deltasFor[:,1:T] . hActsFor[:,0:T-1]^T ; dwtb = deltasBack[:,0:T-1] . hActsBack[:,1:T]^T
             // (brnnet.py:227-230) over the (lo = frame t, hi = frame t+1) row pairs of every utterance
-            SCTC_TRY(side_waits_for_main());         // deltasFor / deltasBack are final
             for (int k = 0; k < 2; ++k) {
                 const sctc_tensor_info& ri = h->tinfo[k == 0 ? wf_index(h) : wb_index(h)];
                 GemmArgs g = gemm_defaults();
@@ -857,33 +806,20 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
                 int splits = 1;
                 gemm_plan_splits(g.M, g.N, std::max(g.K, 1), &splits, g.prec);
                 g.splits = splits;
-                SCTC_TRY(launch_gemm_f32(g, ws));
-                SCTC_HIP_TRY(hipEventRecord(h->grad_ev[k == 0 ? wf_index(h) : wb_index(h)], ws));
+                SCTC_TRY(launch_gemm_f32(g, s));
+                SCTC_HIP_TRY(hipEventRecord(h->grad_ev[k == 0 ? wf_index(h) : wb_index(h)], s));
             }
             // deltasOut = deltasFor + deltasBack, brnnet.py:233
             pt.begin(SCTC_PHASE_OTHER);
-            if (h16) SCTC_TRY(launch_add16(d_out, h->dF, h->dBk, nullptr, bufs16[which & 1], N * LD(h->Hp), s));
+            if (h16) SCTC_TRY(launch_add16(d_out, h->dF, h->dBk, nullptr, bufs16[which], N * LD(h->Hp), s));
             else SCTC_TRY(launch_add(d_out, h->dF, h->dBk, N * LD(h->Hp), s));
         }
         d_in = d_out;
-        d_in16 = bufs16[which & 1];
+        d_in16 = bufs16[which];
         d_in_ld = LD(h->Hp);
-        which = (which + 1) % nbuf;
-        // the buffer the NEXT delta propagation writes was d_in two layers ago (three buffers): the
-        // weight-gradient GEMM that read it must be done.  The side stream runs its GEMMs in order, so
-        // it is enough that the weight gradient of the layer before last has finished -- a wait on
-        // everything queued on the side stream up to, not including, this layer's weight gradient
-        // would need one event per layer; waiting for all of it costs the overlap of exactly one pair
-        // per layer only when the side stream has fallen a whole layer behind.
-        if (two && i - 1 >= 1) {
-            // queued so far on the side stream: weight gradients of layers >= i.  The next write goes to
-            // bufs[which], last read as d_in by the weight gradient of layer i+1 (if any).
-            if (i + 1 <= h->NL) SCTC_HIP_TRY(hipStreamWaitEvent(s, h->ev_wdone[(i + 1) & 1], 0));
-        }
-        if (two) SCTC_HIP_TRY(hipEventRecord(h->ev_wdone[i & 1], ws));
+        which ^= 1;
     }
     h->last_delta1 = d_in;
-    SCTC_TRY(main_waits_for_side());   // the caller's stream carries every gradient when it gets here
     return SCTC_OK;
 }
 
@@ -967,20 +903,6 @@ int sctc_brnn_create(const sctc_brnn_config* cfg, float* params_dev, float* grad
             delete h;
             return set_error(SCTC_ERR_HIP, "brnn_create: hipEventCreate failed");
         }
-    if (cfg->train) {
-        const char* ov = getenv("SCTC_BWD_OVERLAP");
-        h->bwd_overlap = ov ? atoi(ov) : 1;
-        bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&h->ev_delta, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&h->ev_wdone[0], hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&h->ev_wdone[1], hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            sctc_brnn_destroy(h);
-            return set_error(SCTC_ERR_HIP, "brnn_create: side stream / events: %s",
-                             hipGetErrorString(hipGetLastError()));
-        }
-    }
     const char* sm = getenv("SCTC_REC_SYNC");
     h->rec_sync_mode = sm ? atoi(sm) : 1;
     const char* rv = getenv("SCTC_REC_VARIANT");
@@ -1002,12 +924,6 @@ int sctc_brnn_destroy(sctc_brnn_t h)
             (void)hipEventDestroy(h->ev[i][1]);
         }
     if (h->ctc_stage) ctc_free_stage(h->ctc_stage);
-    if (h->side) {
-        (void)hipStreamSynchronize(h->side);
-        (void)hipStreamDestroy(h->side);
-    }
-    for (hipEvent_t e : {h->ev_delta, h->ev_side, h->ev_wdone[0], h->ev_wdone[1]})
-        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->grad_ev)
         if (e) (void)hipEventDestroy(e);
     delete h;
