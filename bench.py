@@ -256,7 +256,15 @@ def main():
         net.checkAsync()
         return cost_dev.cpu().numpy(), skip_dev.cpu().numpy().astype(bool)
 
-    def run_steps(n, resident=True):
+    # roofline leg: asynchronous phase timers (sctc_brnn_set_profiling(h, 2)) -- one hipEvent per
+    # kernel group on the compute stream, resolved after each step (every step ends in a host sync
+    # anyway: the costs come back); no sync is added inside a step, so they run DURING the timed steps
+    Lp = _sctc.lib()
+    Lp.sctc_brnn_set_profiling(net._h, 2)
+    phase_acc = np.zeros(len(PHASES))
+    phase_arr = (ctypes.c_float * len(PHASES))()
+
+    def run_steps(n, resident=True, collect=False):
         """n steps.  resident=False: the SURVEY 8(d) pipeline -- every step's features start in
         pinned host memory and are uploaded inside this call, overlapping the previous step"""
         step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
@@ -268,6 +276,9 @@ def main():
                 upload(k + 1)                               # overlaps compute(k)
             cost, skip = compute(k, resident)
             step_ev[k + 1].record(main_stream)
+            if collect:
+                Lp.sctc_brnn_phase_ms(net._h, phase_arr)
+                phase_acc[:] += np.array(list(phase_arr))
         return cost, skip, step_ev
 
     def fence():
@@ -280,7 +291,7 @@ def main():
         run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
-    cost, skip, step_ev = run_steps(args.steps)
+    cost, skip, step_ev = run_steps(args.steps, collect=True)
     fence()
     elapsed = time.perf_counter() - t0
     per_step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
@@ -295,19 +306,17 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline leg: hipEvent phase timers on the compute stream (extra syncs, untimed)
+        # ---- roofline leg: the phase times of the K timed steps themselves
         L = _sctc.lib()
+        ph = dict(zip(PHASES, [float(v) for v in phase_acc / max(1, args.steps)]))
+        # cross-check: one extra step with the exact (synchronising) phase timers
         L.sctc_brnn_set_profiling(net._h, 1)
-        acc = np.zeros(len(PHASES))
-        reps = 3
         arr = (ctypes.c_float * len(PHASES))()
-        for _ in range(reps):
+        if world == 1:
             net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
             L.sctc_brnn_phase_ms(net._h, arr)
-            acc += np.array(list(arr))
+        ph_exact = dict(zip(PHASES, [float(v) for v in arr]))
         L.sctc_brnn_set_profiling(net._h, 0)
-        acc /= reps
-        ph = dict(zip(PHASES, [float(v) for v in acc]))
         tot, gm, rc = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         mb, keep = net._minibatch(feats, Ts, labels)
         L.sctc_brnn_flops(net._h, ctypes.byref(mb), ctypes.byref(tot), ctypes.byref(gm),
@@ -333,11 +342,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (all time-batched GEMMs)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "measured": "hipEvent phase timers on the compute stream around the GEMM launches "
-                                     "of %d extra steps of the same workload run right after the timed "
-                                     "region (the timers add stream syncs, so they are off while `value` "
-                                     "is timed); profiles/r03_bench_kernel_stats.csv is rocprofv3's view "
-                                     "of the same command" % reps,
+                         "measured": "live, inside the %d timed steps: one hipEvent per kernel group on the "
+                                     "compute stream (sctc_brnn_set_profiling(h, 2): recorded asynchronously, "
+                                     "resolved after each step, no sync added); phase_ms_exact_timers is one "
+                                     "extra step with synchronising timers; profiles/r03_bench_kernel_stats.csv "
+                                     "is rocprofv3's view of the same command" % args.steps,
                          "launches_per_step": n_gemm_launches,
                          "avg_launch_ms": gemm_ms / n_gemm_launches,
                          "algorithmic_tflop_per_step": gm.value / 1e12},
@@ -351,6 +360,7 @@ def main():
                              "unit": "GB/s", "frac": ctc_bytes / (ph["ctc"] * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                              "algorithmic_bytes": ctc_bytes, "ms": ph["ctc"]},
             "phase_ms": ph,
+            "phase_ms_exact_timers": ph_exact,
             "ms_per_step_median": median_ms,
             "timing_note": "features resident in HBM when the timed region starts; value = frames / "
                            "wall time of the K steps (barrier + synchronize on both sides, max over "

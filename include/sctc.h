@@ -228,8 +228,11 @@ int sctc_brnn_recurrent_path(sctc_brnn_t h, int32_t* forward_path, int32_t* bptt
  * caller order, each utterance the reference's (outputDim,T) F-order probs */
 int sctc_brnn_forward(sctc_brnn_t h, const sctc_minibatch* mb, float* probs_dev, void* stream);
 
-/* rocprof-free timing hooks: seconds spent in the phases of the last call, measured
- * with hipEvents on `stream` when enabled (adds syncs; for bench.py's roofline leg) */
+/* rocprof-free timing hooks: milliseconds spent in the phases of the last call, measured with hipEvents
+ * on the step's stream.  sctc_brnn_set_profiling(h, 1): exact phase timers that synchronise the
+ * stream at every phase change (perturbing); (h, 2): asynchronous -- one event per phase change is
+ * recorded and only resolved by sctc_brnn_phase_ms after the step, no host sync is added, so it can
+ * stay on while a benchmark times its steps (bench.py's roofline leg); (h, 0): off */
 #define SCTC_PHASE_FWD_GEMM 0
 #define SCTC_PHASE_FWD_REC 1
 #define SCTC_PHASE_CTC 2

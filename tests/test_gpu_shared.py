@@ -295,3 +295,57 @@ def test_one_utterance_per_stream_full_width(mods):
     assert not skips.any()
     for a, b in zip(g_s, tot):
         assert rel(a, b) < 1e-5
+
+
+def test_async_phase_timers(mods):
+    """sctc_brnn_set_profiling(h, 2): one hipEvent per kernel group, recorded without a host sync and
+    resolved after the step -- what bench.py's roofline leg reads DURING its timed steps.  The phase
+    times must add up to the step, agree with the synchronising timers (mode 1) and leave the results
+    untouched."""
+    import ctypes
+    import time
+    _sctc, brnnet, obrnn, torch = mods
+    D, A, H, NL, TL, T, B = 64, 33, 1024, 4, 2, 300, 20
+    np.random.seed(2)
+    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B)
+    net.initParams()
+    rs = np.random.RandomState(2)
+    feats = torch.randn(B * T, D, device="cuda")
+    labs = [rs.randint(1, A, size=T // 10).astype(np.int32) for _ in range(B)]
+    L = _sctc.lib()
+    arr = (ctypes.c_float * 6)()
+
+    def step():
+        c, _, s = net.costAndGradBatch(None, labs, feats_dev=feats, T_b=[T] * B)
+        return c
+
+    c0 = step()
+    g0 = net.grad.flat.clone()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    base = (time.perf_counter() - t0) / 5 * 1e3
+    L.sctc_brnn_set_profiling(net._h, 2)
+    step()
+    t0 = time.perf_counter()
+    acc = np.zeros(6)
+    for _ in range(5):
+        c2 = step()
+        L.sctc_brnn_phase_ms(net._h, arr)
+        acc += np.array(list(arr))
+    with2 = (time.perf_counter() - t0) / 5 * 1e3
+    acc /= 5
+    assert torch.equal(net.grad.flat, g0) and np.array_equal(c0, c2)
+    L.sctc_brnn_set_profiling(net._h, 1)
+    step()
+    L.sctc_brnn_phase_ms(net._h, arr)
+    exact = np.array(list(arr))
+    L.sctc_brnn_set_profiling(net._h, 0)
+    print("async phase timers: step %.2f ms without, %.2f ms with; phases async %s exact %s"
+          % (base, with2, np.round(acc, 3), np.round(exact, 3)))
+    assert (acc >= 0).all() and acc[:5].min() > 0
+    assert abs(acc.sum() - with2) < 0.15 * with2 + 0.3          # the phases ARE the step (host gaps aside)
+    assert with2 < 1.05 * base + 0.2                            # and cost (almost) nothing
+    big = exact > 0.3
+    np.testing.assert_allclose(acc[big], exact[big], rtol=0.15)
