@@ -278,6 +278,9 @@ class NNet:
         if lanes is not None and len(lanes) == 2 * n_streams:
             return lanes
         L = _sctc.lib()
+        for ln in lanes or []:                         # a different stream count: drop the old engines
+            L.sctc_brnn_destroy(ln["h"])
+        self._lanes = None
         cfg = _sctc.BrnnConfig(self.inputDim, self.outputDim, self.layerSize, self.numLayers,
                                self.temporalLayer, int(self.maxBatch), 1,
                                float(self.maxAct) if self.maxAct else 0.0, float(self.reg), 1,

