@@ -508,8 +508,20 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
             stamp(j, 1);
             float4 x[NCQ];
 #pragma unroll
-            for (int u = 0; u < NCQ; ++u)
+            for (int u = 0; u < NCQ; ++u) {
                 x[u] = ld_x(xrsrc, xin, (unsigned)(c_beg + min(u, cnt - 1)) * chunk_stride);
+                // One s_sleep (64 cycles) between two loads.  The CU's address path takes a 1 KiB wave
+                // load every 16 cycles, so four waves pacing themselves at 64 cycles still hand it
+                // work at its full rate -- the last request leaves no later -- but a wave that sleeps
+                // between its loads leaves the SIMD's issue slots to the wave of the OTHER chain that
+                // shares the SIMD and is feeding the matrix pipe at that moment.  Measured (round 3,
+                // tests/gpu_ab_rec.py, five A/B pairs): 6.72-6.92 instead of 6.99-7.13 us per step;
+                // 128 cycles: 7.25; busy-waiting the same 32..80 cycles with s_nop instead: 7.6-9.2 (the
+                // wave keeps its issue slot); s_setprio 1 / 3 around the MFMAs: no effect.
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             __builtin_amdgcn_sched_barrier(0);   // every load ahead of the first MFMA
 #pragma unroll
             for (int u = 0; u < NCQ; ++u) {
