@@ -202,6 +202,18 @@ def sec_fabric():
         print("  tagged 1 KiB payload us/round trip: same %.2f  cross %.2f" % tuple(v[8:10]))
 
 
+def sec_handoff():
+    """is flag-after-drain + immediate plain loads safe? (tools/diag/handoff_probe.hip)"""
+    L = sctc_diag.lib()
+    for rep in range(3):
+        out = (ctypes.c_float * 9)()
+        assert L.sctc_probe_handoff(out, 9, None) == 0, L.sctc_diag_last_error()
+        v = list(out)
+        for m, name in enumerate(("drain + plain loads (shipped protocol)", "NO drain + plain loads", "drain + sc1 loads")):
+            print("handoff %-40s stale dwords %8d of %d   iterations %d   %.2f us/iteration"
+                  % (name, v[3 * m], 15 * 20000 * 256, v[3 * m + 1], v[3 * m + 2]))
+
+
 def sec_mfmarate():
     """sustained fp32 MFMA rate without memory traffic (what the clock under load allows)"""
     L = sctc_diag.lib()
@@ -540,7 +552,7 @@ def sec_recdbg(sync=0, B=32):
 
 def main():
     want = sys.argv[1:] or ["info", "gemm", "ctc", "brnn"]
-    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "gemmstamp": sec_gemmstamp, "gemmk": sec_gemmk, "twostream": sec_twostream, "fabric": sec_fabric, "sgdloop": sec_sgdloop, "mfmarate": sec_mfmarate, "ctc": sec_ctc,
+    table = {"info": sec_info, "gemm": sec_gemm, "gemm2": sec_gemm2, "gemm3": sec_gemm3, "gemmstamp": sec_gemmstamp, "gemmk": sec_gemmk, "twostream": sec_twostream, "fabric": sec_fabric, "handoff": sec_handoff, "sgdloop": sec_sgdloop, "mfmarate": sec_mfmarate, "ctc": sec_ctc,
              "brnn": lambda: sec_brnn("cfg3", 32, 0),
              "brnn1": lambda: sec_brnn("cfg3", 32, 1),
              "recdbg": lambda: sec_recdbg(0), "recdbg1": lambda: sec_recdbg(1), "recdbgB1": lambda: sec_recdbg(1, 1),

@@ -25,6 +25,11 @@ int sctc_probe_fabric(float* results_host, int32_t n_results, void* stream);
  * then the same two with fresh random operands per MFMA group */
 int sctc_probe_mfma(float* results_host, int32_t n_results, void* stream);
 
+/* flag-after-drain hand-off with IMMEDIATE plain loads by 15 consumer workgroups on other XCDs,
+ * 20 000 fresh 1 KiB blocks.  results_host[9]: per mode {stale payload dwords, iterations (-1: timed
+ * out), microseconds per iteration}; mode 0 = the recurrent kernels' protocol (drain, plain loads),
+ * 1 = no drain (must show stale data), 2 = drain + L2-bypassing loads */
+int sctc_probe_handoff(float* results_host, int32_t n_results, void* stream);
 /* n_wgs workgroups of 256 threads that hold their compute units for `microseconds`: the stand-in
  * for a collective kernel on a side stream (one workgroup per channel, like RCCL) */
 int sctc_diag_spin(void* stream, int32_t n_wgs, int32_t microseconds);

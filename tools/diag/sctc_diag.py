@@ -21,5 +21,6 @@ def lib():
         L.sctc_probe_fabric.argtypes = [f32p, ctypes.c_int32, ctypes.c_void_p]
         L.sctc_probe_mfma.argtypes = [f32p, ctypes.c_int32, ctypes.c_void_p]
         L.sctc_diag_spin.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
+        L.sctc_probe_handoff.argtypes = [f32p, ctypes.c_int32, ctypes.c_void_p]
         _lib = L
     return _lib
