@@ -190,7 +190,14 @@ def main():
     # on a 1-GPU box); the real run uses nccl (= RCCL over xGMI), one rank per GPU
     backend = os.environ.get("SCTC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local % torch.cuda.device_count())
-    if world > 1:
+    # SCTC_BENCH_FORCE_DP=1: a single rank takes the data-parallel path anyway (process group,
+    # per-layer all-reduces queued behind the gradient events, barrier + MAX over ranks) -- the
+    # 1-GPU rehearsal of the driver's N>1 launch with the real backend (RCCL)
+    force_dp = world == 1 and os.environ.get("SCTC_BENCH_FORCE_DP", "0") == "1"
+    if force_dp:
+        os.environ["SCTC_DIST_SINGLE_RANK"] = "1"
+        os.environ.setdefault("MASTER_PORT", "29571")
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {}
         if backend == "nccl":                      # bind the communicator to this rank's GPU up front
@@ -214,7 +221,7 @@ def main():
     rs = np.random.RandomState(100 + rank)
     labels = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
     Ts = [T] * B
-    dp = dist_sgd.DataParallel(net) if world > 1 else None
+    dp = dist_sgd.DataParallel(net) if (world > 1 or force_dp) else None
     # "features already in pinned host memory -> H2D -> ..."
     host_feats = torch.empty(B * T, D, dtype=torch.float32).pin_memory()
     host_feats.copy_(feats)
@@ -283,7 +290,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -295,7 +302,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     per_step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
-    if world > 1:
+    if dp is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -312,7 +319,7 @@ def main():
         # cross-check: one extra step with the exact (synchronising) phase timers
         L.sctc_brnn_set_profiling(net._h, 1)
         arr = (ctypes.c_float * len(PHASES))()
-        if world == 1:
+        if dp is None:
             net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
             L.sctc_brnn_phase_ms(net._h, arr)
         ph_exact = dict(zip(PHASES, [float(v) for v in arr]))
@@ -338,7 +345,7 @@ def main():
                        "utterances_per_gpu": B, "frames_per_step": world * B * T,
                        "parallelism": ("dp%d (utterances sharded, per-layer RCCL all-reduce of the "
                                        "weight gradients overlapped with the backward pass)" % world)
-                                      if world > 1 else "single-gpu"},
+                                      if dp is not None else "single-gpu"},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (all time-batched GEMMs)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
@@ -410,7 +417,7 @@ def main():
                 out["roofline_ctc"]["traffic"] = sum(
                     c[k]["fetch_bytes"] + c[k]["write_bytes"]
                     for k in ("softmax_rows_kernel", "ctc_lattice_kernel", "ctc_grad_kernel"))
-        if world == 1 and not args.no_side:
+        if dp is None and not args.no_side:
             # SURVEY 8(d)'s own definition of the metric: features start in pinned host memory every
             # step, H2D on a copy stream, double-buffered against the previous step's compute
             run_steps(2, resident=False)
@@ -432,7 +439,7 @@ def main():
             cfg5_fp16(out, torch)
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
-    if world > 1:
+    if dp is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -36,13 +36,25 @@ def shard_utterances(lengths, world, rank):
     return shards[rank]
 
 
+def _nothing_to_reduce(group=None):
+    """a single-rank job has nothing to exchange -- unless SCTC_DIST_SINGLE_RANK=1 asks for the
+    collectives anyway: a 1-GPU box can then drive the real backend (RCCL communicator,
+    ProcessGroupNCCL's streams and work handles) through exactly the calls an N-rank run makes
+    (tests/test_gpu_run.py::test_rccl_single_rank_*)."""
+    import os
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return True
+    return dist.get_world_size(group) == 1 and os.environ.get("SCTC_DIST_SINGLE_RANK", "0") != "1"
+
+
 def allreduce_flat(flat, side, bucket_elems=DEFAULT_BUCKET_ELEMS, group=None):
     """Sum-all-reduce the 1-D tensor `flat` in place, bucket by bucket, and the small 1-D
     float64 tensor `side` (e.g. [n_valid, cost_sum]).  Works for CUDA (RCCL) and CPU (gloo)
     tensors; asynchronous bucket handles are waited for at the end so that the copies of
     consecutive buckets overlap on the wire."""
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _nothing_to_reduce(group):
         return flat, side
     handles = []
     n = flat.numel()
@@ -68,7 +80,7 @@ def allreduce_overlapped(net, side, group=None, side_stream=None, backward_queue
     import torch
     import torch.distributed as dist
     import _sctc
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _nothing_to_reduce(group):
         return
     L = _sctc.lib()
     flat = net.grad.flat

@@ -182,3 +182,57 @@ def test_overlapped_allreduce_equals_flat_two_ranks(backend):
     assert out["ok"] and out["world"] == 2 and out["buckets"] == 6
     if backend == "gloo":
         assert out["shared_mode"] == 1        # LOCAL_WORLD_SIZE 2 > 1 visible device
+
+
+def _rccl_one_rank_env(port):
+    return dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LOCAL_WORLD_SIZE="1",
+                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                SCTC_DIST_SINGLE_RANK="1")
+
+
+def test_rccl_single_rank_overlapped_allreduce_equals_flat():
+    """RCCL on the one GPU of the box: a ONE-rank `nccl` process group, with
+    SCTC_DIST_SINGLE_RANK=1 so that dist_sgd issues every collective an N-rank run issues.  A
+    one-rank all-reduce moves nothing over xGMI, but the RCCL communicator is created next to the
+    engine, and ProcessGroupNCCL's own streams / work handles (which gloo's CPU-staged collectives
+    do not have) order the per-layer buckets behind the engine's gradient events while the
+    persistent BPTT grid runs: the result must equal the flat all-reduce and the local gradient
+    bit for bit (tests/gpu_dist_equiv.py).  The two-rank twins above need two devices."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(_rccl_one_rank_env(29561), SCTC_DIST_BACKEND="nccl")
+    res = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_dist_equiv.py")], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["ok"] and out["world"] == 1 and out["backend"] == "nccl" and out["buckets"] == 6
+    assert out["shared_mode"] == 0            # one rank per device: no lease
+
+
+def test_bench_single_rank_rccl():
+    """bench.py's data-parallel step (asynchronous costAndGrad, per-layer RCCL all-reduces on the
+    side stream, barrier + MAX over ranks) on a one-rank `nccl` group at the headline layer size:
+    costs equal the single-GPU path's, and the collectives' bookkeeping costs the step < 5 %."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+            "--batch", "8", "--no-side", "--no-cpu-baseline"]
+    outs = {}
+    for mode in ("single", "dp"):
+        env = _rccl_one_rank_env(29562)
+        if mode == "dp":
+            env.update(SCTC_BENCH_FORCE_DP="1", SCTC_BENCH_BACKEND="nccl")
+        else:
+            env.pop("SCTC_DIST_SINGLE_RANK")
+        res = subprocess.run(base, env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+        outs[mode] = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    s, d = outs["single"], outs["dp"]
+    assert d["config"]["parallelism"].startswith("dp1") and s["config"]["parallelism"] == "single-gpu"
+    assert d["cost_mean"] == s["cost_mean"]                 # same kernels, same order: bit-identical costs
+    assert d["cost_check"]["rel_err"] < 1e-4
+    assert d["ms_per_step"] < 1.05 * s["ms_per_step"] + 0.5, (d["ms_per_step"], s["ms_per_step"])
