@@ -190,6 +190,20 @@ def _rccl_one_rank_env(port):
                 SCTC_DIST_SINGLE_RANK="1")
 
 
+def _require_rccl_one_rank(port):
+    """skip (not fail) when the box cannot create a one-rank RCCL communicator at all -- that is the
+    environment's defect (tools/diag/rccl_one_rank_probe.py: init, one all-reduce, barrier);
+    everything after a successful probe is asserted strictly"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = _rccl_one_rank_env(port)
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "diag", "rccl_one_rank_probe.py")],
+                         env=env, capture_output=True, text=True, timeout=300)
+    if res.returncode != 0 or "barrier ok" not in res.stdout:
+        pytest.skip("no one-rank RCCL communicator on this box: " + (res.stderr or res.stdout)[-300:])
+
+
 def test_rccl_single_rank_overlapped_allreduce_equals_flat():
     """RCCL on the one GPU of the box: a ONE-rank `nccl` process group, with
     SCTC_DIST_SINGLE_RANK=1 so that dist_sgd issues every collective an N-rank run issues.  A
@@ -201,6 +215,7 @@ def test_rccl_single_rank_overlapped_allreduce_equals_flat():
     import json
     import subprocess
     import sys
+    _require_rccl_one_rank(29560)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(_rccl_one_rank_env(29561), SCTC_DIST_BACKEND="nccl")
     res = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_dist_equiv.py")], env=env,
@@ -218,6 +233,7 @@ def test_bench_single_rank_rccl():
     import json
     import subprocess
     import sys
+    _require_rccl_one_rank(29564)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
             "--batch", "8", "--no-side", "--no-cpu-baseline"]

@@ -1,5 +1,8 @@
+"""One-rank RCCL probe: process group on GPU 0, one all-reduce, one barrier (tests/test_gpu_run.py
+uses it to tell a box without a working RCCL from a defect of this package)."""
 import os, time, torch, torch.distributed as dist
-os.environ.setdefault("MASTER_ADDR","127.0.0.1"); os.environ.setdefault("MASTER_PORT","29611")
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29611")
 t0=time.time()
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda",0))
