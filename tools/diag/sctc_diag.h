@@ -34,6 +34,14 @@ int sctc_probe_handoff(float* results_host, int32_t n_results, void* stream);
  * for a collective kernel on a side stream (one workgroup per channel, like RCCL) */
 int sctc_diag_spin(void* stream, int32_t n_wgs, int32_t microseconds);
 
+/* a stream whose kernels run only on the compute units whose bit is set in mask_words (n_words x 32
+ * bits; hipExtStreamCreateWithCUMask) */
+int sctc_diag_stream_cu_mask(const uint32_t* mask_words, int32_t n_words, void** stream_out);
+int sctc_diag_stream_destroy(void* stream);
+/* n_wgs workgroups of 256 threads, each holding its CU for hold_us: out_host[4 * i + {0,1,2,3}] =
+ * XCC id, shader engine, shader array, CU id of workgroup i (synchronous) */
+int sctc_diag_where(int32_t* out_host, int32_t n_wgs, int32_t hold_us, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,5 +22,10 @@ def lib():
         L.sctc_probe_mfma.argtypes = [f32p, ctypes.c_int32, ctypes.c_void_p]
         L.sctc_diag_spin.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]
         L.sctc_probe_handoff.argtypes = [f32p, ctypes.c_int32, ctypes.c_void_p]
+        L.sctc_diag_stream_cu_mask.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int32,
+                                               ctypes.POINTER(ctypes.c_void_p)]
+        L.sctc_diag_stream_destroy.argtypes = [ctypes.c_void_p]
+        L.sctc_diag_where.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32,
+                                      ctypes.c_void_p]
         _lib = L
     return _lib
