@@ -539,6 +539,38 @@ def sec_recdbg(sync=0, B=32):
         print("   flags-seen -> published duration: median %.2f, p90 %.2f, max %.2f us; by XCD median:" %
               (np.median(dur), np.percentile(dur, 90), dur.max()),
               " ".join("%.2f" % np.median(dur[ids % 8 == x]) for x in range(8)))
+    # placement (variant build -DSCTC_REC_WHERE): which workgroups share a compute unit
+    for ps, pname in enumerate(("forward", "bptt")):
+        a = both[ps, 256:].reshape(512, 8)
+        ids = np.nonzero(a[:, 7] != 0)[0]
+        w = a[ids]
+        if not w[:, 6].any():
+            continue
+        t0 = w[:, 0].min()
+        pub = (w[:, 5] - t0) * 0.01
+        dur = (w[:, 5] - w[:, 1]) * 0.01
+        groups = {}
+        for n, key in enumerate(w[:, 6]):
+            groups.setdefault(int(key), []).append(n)
+        sizes = np.array([len(v) for v in groups.values()])
+        per_xcc = {}
+        for key, v in groups.items():
+            per_xcc.setdefault(key >> 16, []).append(len(v))
+        print("%s placement: %d CUs hold workgroups: %s; CUs per XCC / workgroups: %s" % (
+            pname, len(groups), {int(k): int((sizes == k).sum()) for k in sorted(set(sizes))},
+            " ".join("%d:%d/%d" % (x, len(v), sum(v)) for x, v in sorted(per_xcc.items()))))
+        alone = [v[0] for v in groups.values() if len(v) == 1]
+        pairs = [v for v in groups.values() if len(v) == 2]
+        same = [v for v in pairs if w[v[0], 7] == w[v[1], 7]]
+        paired = [n for v in pairs for n in v]
+        print("   alone on a CU: %d wgs, flags-seen->published median %.2f us, publish median %.2f / max %.2f" % (
+            len(alone), np.median(dur[alone]) if alone else -1, np.median(pub[alone]) if alone else -1,
+            pub[alone].max() if alone else -1))
+        print("   two on a CU: %d wgs (%d pairs of the SAME chain), flags-seen->published median %.2f us, publish median %.2f / max %.2f" % (
+            len(paired), len(same), np.median(dur[paired]) if paired else -1, np.median(pub[paired]) if paired else -1,
+            pub[paired].max() if paired else -1))
+        blocks_alone = sorted(int(ids[n]) for n in alone)
+        print("   blocks alone:", blocks_alone[:64])
     names = ["wait", "load+mfma", "lds-reduce", "epilogue", "publish"]
     for ps, pname in enumerate(("forward", "bptt")):
         for w in range(2):
