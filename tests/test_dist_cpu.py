@@ -97,3 +97,37 @@ def test_gloo_world2_mean_gradient_matches_oracle():
     np.testing.assert_allclose(f0, ref, rtol=2e-5, atol=1e-6)
     # mean-gradient convention of ctc/nnet.py:106-124
     np.testing.assert_allclose(f0 / s0[0], ref / n_valid, rtol=2e-5, atol=1e-6)
+
+
+def _single_rank_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dist_sgd
+    flat = torch.arange(1000, dtype=torch.float32) * 0.5
+    side = torch.tensor([3.0, 7.5], dtype=torch.float64)
+    ref = flat.clone()
+    # default: a single rank has nothing to exchange and issues no collective
+    os.environ.pop("SCTC_DIST_SINGLE_RANK", None)
+    assert dist_sgd._nothing_to_reduce()
+    dist_sgd.allreduce_flat(flat, side, bucket_elems=300)
+    assert torch.equal(flat, ref)
+    # SCTC_DIST_SINGLE_RANK=1: the collectives run (bucketed, asynchronous handles) and sum over one rank
+    os.environ["SCTC_DIST_SINGLE_RANK"] = "1"
+    assert not dist_sgd._nothing_to_reduce()
+    dist_sgd.allreduce_flat(flat, side, bucket_elems=300)
+    out.put((bool(torch.equal(flat, ref)), side.tolist()))
+    dist.destroy_process_group()
+
+
+def test_single_rank_collectives_switch():
+    """dist_sgd on one rank: no collective by default, every collective of an N-rank run with
+    SCTC_DIST_SINGLE_RANK=1 (the switch the 1-GPU RCCL tests use, tests/test_gpu_run.py)"""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_single_rank_worker, args=(0, 1, _free_port(), out))
+    p.start()
+    same, side = out.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert same and side == [3.0, 7.5]
