@@ -699,8 +699,8 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             // The weight gradients of the layers above the temporal layer (loop indices i >= TL: W_{TL+1}
             // .. W_{NL+1}) finish BEFORE the BPTT recurrence starts.  A collective
             // started on their event would hold compute units while the persistent BPTT grid is being
-            // placed (all of its workgroups must be resident at once; two-chain kernel: every register
-            // of 228 CUs): their events are recorded after BPTT has retired instead (below), so a
+            // placed (all of its workgroups must be resident at once; the two-chain kernel takes every
+            // register of 200 CUs and half of the other 56): their events are recorded after BPTT has retired instead (below), so a
             // data-parallel caller's all-reduces only ever overlap the time-batched GEMMs.
             if (!(h->TL > 0 && i >= h->TL))
                 SCTC_HIP_TRY(hipEventRecord(h->grad_ev[weight_index(h, i)], s));

@@ -651,16 +651,26 @@ static int launch_lattice_k(const CtcLatticeArgs<RI>& a, int B, int NA, int lazy
 
 // Lattice shape for label rows of up to max_L = 2U+1 states: K states per lane, W waves per
 // (utterance, pass).  Up to 256 states one wave holds everything (no cross-wave traffic); longer
-// rows are spread over 4 waves so that a frame costs K/4 as many dependent float64 operations.
+// rows are spread over 4 waves so that a frame costs K/4 as many dependent float64 operations, and
+// rows of more than 1024 states over 8 waves (two per SIMD): at T = 8000 / U = 800 a frame costs 0.65
+// instead of 0.73 us with 4 states per lane instead of 8 (round 3; 16 waves x 2 states: 1.2 us --
+// four waves per SIMD meet at the frame's barrier; 8 waves x 2 states for 513..1024 states: 2-4 %
+// slower than 4 waves x 4).  Costs and gradients agree to all printed digits
+// between the shapes (tests/gpu_ctc_shape.py); the band sum is taken in another order, so the last
+// bits of a lattice may differ from one shape to the other.
 int ctc_lattice_shape(int max_L, int* waves)
 {
-    const char* force = getenv("SCTC_CTC_WAVES");   // diagnostics: 1 / 4
+    const char* force = getenv("SCTC_CTC_WAVES");   // diagnostics: 1 / 4 / 8
     const int fw = force ? atoi(force) : 0;
     if ((fw == 0 && max_L <= 256) || fw == 1) {
         *waves = 1;
         for (int k = 2; k <= 32; k *= 2)
             if (max_L <= 64 * k) return k;
         return 0;
+    }
+    if (fw == 8 || (fw == 0 && max_L > 1024)) {
+        *waves = 8;
+        return max_L <= 1024 ? 2 : (max_L <= 2048 ? 4 : 0);
     }
     *waves = 4;
     for (int k = 2; k <= 8; k *= 2)
@@ -673,6 +683,12 @@ int launch_ctc_lattice(const CtcLatticeArgs<RI>& a, int B, int K, int W, int laz
 {
     using R = RI;
     const int NA = a.A <= 64 ? 1 : (a.A <= 128 ? 2 : 4);
+    if (W == 8) {
+        switch (K) {
+            case 2: return launch_lattice_k<R, 2, 8>(a, B, NA, lazy, stream);
+            case 4: return launch_lattice_k<R, 4, 8>(a, B, NA, lazy, stream);
+        }
+    }
     if (W == 4) {
         switch (K) {
             case 2: return launch_lattice_k<R, 2, 4>(a, B, NA, lazy, stream);

@@ -373,7 +373,10 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
 // the matrix pipes idle during everything but the MFMAs.  Different utterances never interact,
 // so the minibatch splits into independent chains of 16 utterances.  Here a workgroup owns
 // 16 output units x ONE utterance tile, and two workgroups (of different chains) share a CU:
-// while one waits for its exchange the other one computes.  Per workgroup: 4 waves = 4 K
+// while one waits for its exchange the other one computes.  (The dispatcher does not pack them
+// two by two: at H = 1824 it puts the first 32 workgroups of an XCC on 32 different CUs and the
+// other 25 next to them -- 200 CUs hold two workgroups, 56 hold one, none is idle; a workgroup
+// alone on its CU needs 3.8 us from "flags seen" to "published", one that shares needs 5.1 us.)  Per workgroup: 4 waves = 4 K
 // quarters (the 114 chunks of H = 1824 split 29/29/28/28); the 16 x H weight slab no longer
 // fits twice into 160 KiB of LDS, so each wave keeps NREG of its chunks in registers and the
 // rest in a wave-private LDS region.  Exchange traffic per CU and step is unchanged (2 x 16
@@ -470,6 +473,16 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
         if (p.debug && tid == 0 && j == 70) {   // every workgroup: global 100 MHz clock, chain tag
             p.debug[REC_DEBUG_ALL_OFF + blockIdx.x * 8 + k] = (unsigned)wall_clock64();
             if (k == 0) p.debug[REC_DEBUG_ALL_OFF + blockIdx.x * 8 + 7] = 1u + (unsigned)chain;
+#ifdef SCTC_REC_WHERE
+            // placement (diagnostics build, tests/gpu_diag.py recdbg1): XCC id and HW_ID bits 15:8 (cu 11:8,
+            // sh 12, se 15:13) of the CU this workgroup runs on.  Measured (round 3): the dispatcher spreads
+            // the 57 workgroups of an XCC over all 32 CUs -- 25 CUs hold two (always of different chains),
+            // 7 hold one (blocks 200..255 of the grid), none is idle.
+            if (k == 0)
+                p.debug[REC_DEBUG_ALL_OFF + blockIdx.x * 8 + 6] =
+                    ((__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 0xf) << 16) |
+                    ((__builtin_amdgcn_s_getreg(4 | (0 << 6) | ((32 - 1) << 11)) >> 8) & 0xff);
+#endif
         }
     };
 

@@ -539,7 +539,7 @@ def sec_recdbg(sync=0, B=32):
         print("   flags-seen -> published duration: median %.2f, p90 %.2f, max %.2f us; by XCD median:" %
               (np.median(dur), np.percentile(dur, 90), dur.max()),
               " ".join("%.2f" % np.median(dur[ids % 8 == x]) for x in range(8)))
-    # placement (variant build -DSCTC_REC_WHERE): which workgroups share a compute unit
+    # placement (tools/build_variant.sh where recurrent.hip "-DSCTC_REC_WHERE"): which workgroups share a compute unit
     for ps, pname in enumerate(("forward", "bptt")):
         a = both[ps, 256:].reshape(512, 8)
         ids = np.nonzero(a[:, 7] != 0)[0]
