@@ -165,8 +165,10 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
     // W waves share one (utterance, pass): state s lives in global lane gl = s / K.  The two
     // cross-wave couplings of a frame go through LDS: the neighbour state of a wave's lane 0
     // (last state of the previous wave) and the band sum of a rescaling frame.
-    __shared__ double bnd[2][W > 1 ? W : 1];
-    __shared__ double part[2][W > 1 ? W : 1];
+    // per frame parity and wave: {band-sum partial, last state's unnormalised value} -- one 16-byte slot,
+    // written by lane 63 with one ds_write_b128
+    __shared__ __attribute__((aligned(16))) double xw[2][W > 1 ? W : 1][2];
+    double bprev = 0.0;   // W > 1: the previous wave's last state as of the last exchange (read right behind its barrier)
     using R = double;
     static_assert(K % 2 == 0 && K >= 2, "K must be even");
     constexpr int KH = K / 2;
@@ -304,20 +306,30 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
         if constexpr (W == 1) {
             return ws;
         } else {
-            if (lane == 0) part[tau & 1][wave] = ws;
-            if (lane == 63) bnd[tau & 1][wave] = last_unnorm;
+            if (lane == 63) {
+                *reinterpret_cast<double2*>(&xw[tau & 1][wave][0]) = make_double2(ws, last_unnorm);
+            }
             lds_barrier();
-            R c = part[tau & 1][0];
+            // every read behind the barrier is issued at once: the W partials and the boundary state the
+            // NEXT frame needs (it used to be a dependent LDS read at the head of that frame); the partials
+            // are summed as a tree in a fixed order
+            R pw[W];
 #pragma unroll
-            for (int w = 1; w < W; ++w) c += part[tau & 1][w];
-            return c;
+            for (int w = 0; w < W; ++w) pw[w] = xw[tau & 1][w][0];
+            bprev = xw[tau & 1][wave > 0 ? wave - 1 : 0][1];
+#pragma unroll
+            for (int st = 1; st < W; st *= 2)
+#pragma unroll
+                for (int w = 0; w + st < W; w += 2 * st) pw[w] += pw[w + st];
+            return pw[0];
         }
     };
     // frames without a rescale (lazy schedule): the boundary state alone
     auto publish = [&](R last, int tau) {
         if constexpr (W > 1) {
-            if (lane == 63) bnd[tau & 1][wave] = last;
+            if (lane == 63) xw[tau & 1][wave][1] = last;
             lds_barrier();
+            bprev = xw[tau & 1][wave > 0 ? wave - 1 : 0][1];
         }
     };
     // last state of global lane gl - 1 as of the previous frame (all threads call, start of a frame);
@@ -325,7 +337,9 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
     auto shift_in = [&](const R (&v)[K], int tau, R rprev) -> R {
         R prev = lane_shr1(v[K - 1]);
         if constexpr (W > 1) {
-            if (lane == 0 && wave > 0) prev = bnd[(tau - 1) & 1][wave - 1] * rprev;
+            (void)tau;
+            const R across = bprev * rprev;          // the very product the owning wave stored
+            prev = (lane == 0 && wave > 0) ? across : prev;
         }
         return prev;
     };

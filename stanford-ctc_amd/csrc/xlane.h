@@ -48,19 +48,24 @@ __device__ __forceinline__ double lane_shr1(double v)
 #endif
 }
 
+// Lanes that receive no source add 0.  With every row enabled (ROW_MASK 0xF) that is what bound_ctrl
+// delivers (a shifted-in lane reads 0) and the `old` operand is dead -- no register pair has to be zeroed
+// in front of the move (two v_mov + a hazard nop per stage; it matters where the wave is issue-bound: the
+// 8-wave CTC lattice).  With rows masked off (the row_bcast stages) the disabled rows keep `old` = 0.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v)
 {
-    // lanes that receive no source (shifted-in / masked rows) add 0
-    return v + __int_as_float(dpp_i32<CTRL, ROW_MASK, 0xF, false>(0, __float_as_int(v)));
+    constexpr bool BC = ROW_MASK == 0xF;
+    return v + __int_as_float(dpp_i32<CTRL, ROW_MASK, 0xF, BC>(0, __float_as_int(v)));
 }
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add(double v)
 {
+    constexpr bool BC = ROW_MASK == 0xF;
     long long b = __double_as_longlong(v);
-    int lo = dpp_i32<CTRL, ROW_MASK, 0xF, false>(0, (int)(b & 0xffffffffll));
-    int hi = dpp_i32<CTRL, ROW_MASK, 0xF, false>(0, (int)(b >> 32));
+    int lo = dpp_i32<CTRL, ROW_MASK, 0xF, BC>(0, (int)(b & 0xffffffffll));
+    int hi = dpp_i32<CTRL, ROW_MASK, 0xF, BC>(0, (int)(b >> 32));
     return v + __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
