@@ -569,6 +569,11 @@ def sec_recdbg(sync=0, B=32):
         print("   two on a CU: %d wgs (%d pairs of the SAME chain), flags-seen->published median %.2f us, publish median %.2f / max %.2f" % (
             len(paired), len(same), np.median(dur[paired]) if paired else -1, np.median(pub[paired]) if paired else -1,
             pub[paired].max() if paired else -1))
+        ph_names = ["start->flags seen", "flags seen->mfma done", "mfma done->reduced", "reduced->stored", "stored->published"]
+        for nm, grp in (("alone", alone), ("two on a CU", paired)):
+            if grp:
+                d = np.diff(w[grp][:, :6], axis=1) * 0.01
+                print("   %-12s phases (us, median): %s" % (nm, ", ".join("%s %.2f" % (n, v) for n, v in zip(ph_names, np.median(d, axis=0)))))
         blocks_alone = sorted(int(ids[n]) for n in alone)
         print("   blocks alone:", blocks_alone[:64])
     names = ["wait", "load+mfma", "lds-reduce", "epilogue", "publish"]
