@@ -176,7 +176,13 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
     // Frames of probabilities prefetched per block.  gfx950 counts loads and stores in ONE
     // in-order counter (vmcnt), so waiting for a block's prefetch also waits for the lattice
     // rows stored before it: one HBM write latency per block.  Long blocks amortise it.
-    constexpr int PF = K <= 4 ? 32 : (K <= 8 ? 16 : 8);
+    // (8 waves = two per SIMD = 256 registers per lane: 32 prefetched frames with their gathered
+    // float64 probabilities no longer fit -- 38..170 spilled registers in the frame loop -- 16 do)
+    // Wide alphabets in float64 (32 bytes per prefetched frame and lane) get shorter blocks for the same reason.
+    constexpr int ROWB = NA * (int)sizeof(RI);
+    constexpr int PF_K = K <= 4 ? 32 : (K <= 8 ? 16 : 8);
+    constexpr int PF_A = ROWB >= 32 ? 8 : (ROWB >= 16 ? 16 : 32);
+    constexpr int PF = W >= 8 ? (ROWB <= 4 ? 16 : 8) : (PF_K < PF_A ? PF_K : PF_A);
     const int b = blockIdx.x;
     const int dir = blockIdx.y;  // 0: alpha, 1: beta (== alpha of the reversed problem)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = threadIdx.x;
