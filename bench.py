@@ -14,9 +14,11 @@ processes its own 32 utterances; the only exchange is the sum of the weight grad
 The metric is SURVEY 8(d)'s: the features of a step start in PINNED HOST memory; their H2D copy
 runs on a copy stream into one of two device buffers, so the upload of step k+1 overlaps the
 compute of step k (all K uploads sit inside the timed region).  `value` = frames / wall time of
-exactly K steps (max over ranks); the median per-step time, the HBM-resident rate and the
-non-overlapped PCIe rate are side fields.  One utterance's cost is checked against the float64
-oracle outside the timed region: a mismatch fails the run.
+exactly K such steps (barrier + synchronize on both sides, max over ranks).  The same K steps with
+the features already RESIDENT in HBM are the side field `hbm_resident` (what the kernels alone
+do; round 3 reported that as `value`, rounds 1-2 and 4 the pinned-host pipeline), both step times
+are repeated in `timing` at the head of the line.  One utterance's cost is checked against the
+float64 oracle outside the timed region: a mismatch fails the run.
 """
 import argparse
 import ctypes
@@ -134,7 +136,8 @@ def cpu_baseline(cfg, budget_s=75.0):
             "sample": "best of a sweep over processes x BLAS threads on the %d host cores: %d utterances "
                       "of T=%d (cfg-3 shape, a fraction of the headline length) in %d processes x %d "
                       "threads sharing one copy of the weights, %.1f s wall, %.1f s mean per utterance; "
-                      "NumPy f64 BRNN oracle + C CTC oracle; sweep: %s"
+                      "NumPy f64 BRNN oracle + C CTC oracle; memory-bound on the host, run-to-run and "
+                      "box-to-box spread +-15 %% (1.9-2.5 k frames/s over rounds 2-3); sweep: %s"
                       % (ncpu, best[1], best[5], best[1], best[2], best[3], best[4],
                          ", ".join("%dx%d -> %.0f frames/s" % (p, t, v) for v, p, t, _, _, _ in tried)) +
                       ("" if every_core is None else
@@ -237,6 +240,12 @@ def main():
     labels = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
     Ts = [T] * B
     dp = dist_sgd.DataParallel(net) if (world > 1 or force_dp) else None
+    if dp is not None and world > 1 and backend != "gloo":
+        # one rank per PHYSICAL GPU (the ranks exchanged PCI bus ids in DataParallel.__init__): two RCCL
+        # ranks on one device would be refused by RCCL later with a less readable message
+        assert len(set(dp.device_ids)) == world and not dp.shared_device, \
+            "bench.py --gpus %d: ranks share a GPU (%s); SCTC_BENCH_BACKEND=gloo rehearses on fewer devices" \
+            % (world, dp.device_ids)
     # "features already in pinned host memory -> H2D -> ..."
     host_feats = torch.empty(B * T, D, dtype=torch.float32).pin_memory()
     host_feats.copy_(feats)
@@ -310,17 +319,24 @@ def main():
         torch.cuda.synchronize()
 
     if args.warmup:
-        run_steps(args.warmup)
+        run_steps(args.warmup, resident=False)
     fence()
     t0 = time.perf_counter()
-    cost, skip, step_ev = run_steps(args.steps, collect=True)
+    cost, skip, step_ev = run_steps(args.steps, resident=False, collect=True)
     fence()
     elapsed = time.perf_counter() - t0
+    # side field: the same K steps with the features already resident in HBM
+    run_steps(1, resident=True)
+    fence()
+    t0 = time.perf_counter()
+    run_steps(args.steps, resident=True)
+    fence()
+    elapsed_res = time.perf_counter() - t0
     per_step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
     if dp is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, elapsed_res], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_res = float(t[0].item()), float(t[1].item())
     frames_total = world * B * T * args.steps
     ms_per_step = elapsed / args.steps * 1e3
     median_ms = per_step_ms[len(per_step_ms) // 2] if len(per_step_ms) % 2 else \
@@ -354,13 +370,20 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "timing": {"value_is": "pinned_host_overlapped", "pinned_host_overlapped_ms": ms_per_step,
+                       "hbm_resident_ms": elapsed_res / args.steps * 1e3,
+                       "hbm_resident_frames_per_s": frames_total / elapsed_res},
             "config": {"workload": "WSJ-shape cfg-3: T=1000 A=33 5x1824 BRNN (temporalLayer 3, "
                                    "inputDim 483) U=100, minibatch %d per GPU, one costAndGrad per "
                                    "step" % B,
                        "utterances_per_gpu": B, "frames_per_step": world * B * T,
                        "parallelism": ("dp%d (utterances sharded, per-layer RCCL all-reduce of the "
                                        "weight gradients overlapped with the backward pass)" % world)
-                                      if dp is not None else "single-gpu"},
+                                      if dp is not None else "single-gpu",
+                       "backend": backend if dp is not None else None,
+                       "rccl_ranks": (["%d:%s:%s" % (r, i[0], i[1]) for r, i in enumerate(dp.device_ids)]
+                                      if dp is not None else None),
+                       "shared_device_mode": bool(dp.shared_device) if dp is not None else False},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (all time-batched GEMMs)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
@@ -384,10 +407,16 @@ def main():
             "phase_ms": ph,
             "phase_ms_exact_timers": ph_exact,
             "ms_per_step_median": median_ms,
-            "timing_note": "features resident in HBM when the timed region starts; value = frames / "
-                           "wall time of the K steps (barrier + synchronize on both sides, max over "
-                           "ranks), median = hipEvent time between step ends; the host-to-device "
-                           "pipeline is the side field pinned_host_overlapped",
+            "timing_note": "SURVEY 8(d) pipeline: every step's features start in PINNED HOST memory, H2D "
+                           "(%.1f MB per step) on a copy stream into one of two device buffers, "
+                           "overlapping the previous step's compute, all K uploads inside the timed "
+                           "region; value = frames / wall time of the K steps (barrier + synchronize on "
+                           "both sides, max over ranks), median = hipEvent time between step ends; the "
+                           "same K steps on HBM-resident features are the side field hbm_resident "
+                           "(round 3 reported that one as value)" % (B * T * D * 4 / 1e6),
+            "hbm_resident": {"value": frames_total / elapsed_res, "unit": "frames/s",
+                             "ms_per_step": elapsed_res / args.steps * 1e3,
+                             "note": "features resident in HBM when the timed region starts"},
             "cost_mean": float(np.mean(cost[~skip])) if (~skip).any() else None,
         }
         out["cost_check"] = oracle_cost_check(cfg, net, host_feats[:T].numpy(), labels[0],
@@ -433,20 +462,8 @@ def main():
                     c[k]["fetch_bytes"] + c[k]["write_bytes"]
                     for k in ("softmax_rows_kernel", "ctc_lattice_kernel", "ctc_grad_kernel"))
         if dp is None and not args.no_side:
-            # SURVEY 8(d)'s own definition of the metric: features start in pinned host memory every
-            # step, H2D on a copy stream, double-buffered against the previous step's compute
-            run_steps(2, resident=False)
-            fence()
-            t0 = time.perf_counter()
-            run_steps(args.steps, resident=False)
-            fence()
-            dt = (time.perf_counter() - t0) / args.steps
-            out["pinned_host_overlapped"] = {
-                "value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
-                "h2d_bytes_per_step": B * T * D * 4,
-                "note": "every step's features start in pinned host memory; H2D on a copy stream, "
-                        "double-buffered against the previous step's compute (all uploads timed)"}
             side_measurements(out, net, feats, labels, Ts, rs, torch, B, T, D)
+            recurrent_by_minibatch(out, torch, cfg)
             f32_split_bf16x3(out, torch, cfg, labels, feats, net)
             ctc_saturation(out, torch, A, T, U)
             del net, feats, dev_bufs
@@ -532,11 +549,54 @@ def side_measurements(out, net, feats, labels, Ts, rs, torch, B, T, D):
         dt = timed(lambda: net.costAndGradStreams(None, labels[:n8], n_streams=ns, feats_dev=feats[:n8 * T],
                                                   T_b=[T] * n8), 2)
         per[ns] = n8 * T / dt
+    best_ns = max(per, key=per.get)
     out["one_utterance_per_stream"] = {
-        "value": per[2], "unit": "frames/s", "streams": 2, "utterances": n8,
+        "value": per[best_ns], "unit": "frames/s", "streams": best_ns, "utterances": n8,
         "by_streams": {str(k): v for k, v in per.items()},
         "note": "every utterance its own minibatch-1 costAndGrad on one of n HIP streams, gradients "
                 "summed; the packed time-major minibatch (`value`) is the faster way to use the part"}
+
+
+def recurrent_by_minibatch(out, torch, cfg):
+    """MFMA utilisation of the recurrent TIME-STEP contraction as a function of the
+    minibatch (the time-batched GEMMs are `roofline`).  cfg-3 layer sizes, utterances of T/4 frames (a
+    time step costs the same at any T), one profiled step per size; FLOPs = 2 directions x (2 H^2 B
+    forward + 2 H^2 B BPTT) per time step, against the dense fp32 MFMA peak."""
+    from nnets import brnnet
+    import _sctc
+    D, A, H, NL, TL = (cfg[k] for k in ("D", "A", "H", "NL", "TL"))
+    T = max(64, cfg["T"] // 4)
+    L = _sctc.lib()
+    res = {}
+    for B in (16, 32, 64, 128):
+        np.random.seed(0)
+        net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B)
+        net.initParams()
+        g = torch.Generator(device="cuda")
+        g.manual_seed(9)
+        feats = torch.randn(B * T, D, device="cuda", generator=g)
+        rs = np.random.RandomState(9)
+        labels = [rs.randint(1, A, size=max(1, T // 10)).astype(np.int32) for _ in range(B)]
+        Ts = [T] * B
+        net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+        L.sctc_brnn_set_profiling(net._h, 1)
+        acc = np.zeros(len(PHASES))
+        arr = (ctypes.c_float * len(PHASES))()
+        n = 3
+        for _ in range(n):
+            net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+            L.sctc_brnn_phase_ms(net._h, arr)
+            acc += np.array(list(arr))
+        L.sctc_brnn_set_profiling(net._h, 0)
+        ph = dict(zip(PHASES, acc / n))
+        us = (ph["fwd_rec"] + ph["bwd_rec"]) * 1e3 / (2 * (T - 1))
+        flops_per_time_step = 2 * 2.0 * H * H * B          # both directions, one pass
+        res[str(B)] = {"us_per_time_step": us, "tflops": flops_per_time_step / (us * 1e-6) / 1e12,
+                       "frac_of_f32_mfma_peak": flops_per_time_step / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                       "path": list(net.recurrentPath())}
+        del net, feats
+        torch.cuda.empty_cache()
+    out["roofline_recurrent"]["by_minibatch"] = res
 
 
 def ctc_saturation(out, torch, A, T, U):

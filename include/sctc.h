@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SCTC_ABI_VERSION 3
+#define SCTC_ABI_VERSION 4
 
 #define SCTC_OK 0
 #define SCTC_ERR_ARG (-1)       /* bad argument (the reference raises ValueError/AssertionError) */
@@ -63,11 +63,17 @@ int sctc_device_info(int* compute_units, int* lds_bytes_per_cu, int64_t* total_m
  * every workgroup of a pass resident at once.  With shared-device mode on, each persistent launch
  * runs under an inter-process lease (flock on a per-device file in /dev/shm), synchronously: two
  * ranks on one GPU take turns instead of dead-locking each other.  Initial value: environment
- * variable SCTC_SHARED_DEVICE (the Python mirror sets it when the local ranks outnumber the
- * visible devices); switched on automatically, for the rest of the process, by the first
- * SCTC_ERR_TIMEOUT.  One rank per GPU (the default) pays nothing. */
+ * variable SCTC_SHARED_DEVICE (the Python mirror sets it when two ranks of a job report the same
+ * physical device, sctc_device_pci_bus_id below); switched on automatically, for the rest of the
+ * process, by the first SCTC_ERR_TIMEOUT (one line on stderr).  One rank per GPU pays nothing. */
 int sctc_set_shared_device(int32_t on);
 int sctc_shared_device(void);
+/* PCI bus id ("0000:c1:00.0") of HIP device `device` (-1: the current one): the PHYSICAL identity of
+ * the GPU, the same string in every process whatever HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES
+ * renumbering the launcher applied.  The reference selects its GPU by ordinal (runNNet.py:117-120,
+ * cm.cuda_set_device) and never needs to know; the data-parallel ranks exchange this id to find out
+ * whether two of them sit on one GPU (stanford-ctc_amd/dist_sgd.py).  Writes a NUL-terminated string. */
+int sctc_device_pci_bus_id(int32_t device, char* out, int32_t out_len);
 
 /* ---- CTC: ctc_fast/ctc-loss/ctc_fast.pyx ------------------------------- */
 

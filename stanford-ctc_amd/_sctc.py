@@ -58,6 +58,7 @@ PROTOTYPES = {
     "sctc_device_info": (ctypes.c_int, [c_i32p, c_i32p, c_i64p, ctypes.c_char_p, ctypes.c_int]),
     "sctc_set_shared_device": (ctypes.c_int, [ctypes.c_int32]),
     "sctc_shared_device": (ctypes.c_int, []),
+    "sctc_device_pci_bus_id": (ctypes.c_int, [ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]),
     "sctc_ctc_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(CtcBatch)]),
     "sctc_ctc_loss_batch": (ctypes.c_int, [ctypes.POINTER(CtcBatch), vp, vp, vp, vp, vp,
                                            ctypes.c_size_t, vp]),
@@ -116,21 +117,69 @@ class SctcError(RuntimeError):
     pass
 
 
-def _ranks_share_a_device():
-    """True when torch.distributed.run put more local ranks on this node than there are visible
-    GPUs (e.g. a 2-rank rehearsal on a 1-GPU box): the persistent recurrent launches of the ranks
-    must then take turns (sctc_set_shared_device, include/sctc.h)."""
+_VISIBILITY_VARS = ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL")
+
+
+def _ranks_probably_share_a_device():
+    """Provisional guess at load time, before any process group exists: torch.distributed.run put
+    more local ranks on this node than there are visible GPUs AND no launcher restricted this
+    rank's view of the devices (with HIP_VISIBLE_DEVICES=$LOCAL_RANK every rank of an 8-GPU node
+    sees ONE device, and counting would call that sharing).  The authoritative decision is
+    resolve_shared_device(): the ranks exchange the PCI bus ids of their devices."""
     try:
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
     except ValueError:
         return False
-    if local_world <= 1:
+    if local_world <= 1 or any(v in os.environ for v in _VISIBILITY_VARS):
         return False
     try:
         import torch
         return local_world > max(1, torch.cuda.device_count())
     except Exception:
         return False
+
+
+def device_bus_id(device=-1):
+    """PCI bus id of HIP device `device` (-1: current): the physical identity of the GPU"""
+    buf = ctypes.create_string_buffer(64)
+    check(lib().sctc_device_pci_bus_id(device, buf, 64), "device_pci_bus_id")
+    return buf.value.decode()
+
+
+def shared_device_from_ids(ids, rank):
+    """ids[r] = (hostname, bus id) of rank r.  True iff another rank sits on this rank's GPU."""
+    me = tuple(ids[rank])
+    return sum(1 for x in ids if tuple(x) == me) > 1
+
+
+def resolve_shared_device(group=None, my_id=None, log=True):
+    """Shared-device mode decided by PHYSICAL device identity: every rank
+    contributes (hostname, PCI bus id of its current device) to an all-gather over the process
+    group; the mode is on iff two ranks report the same pair, whatever device ordinals, visibility
+    masks or LOCAL_WORLD_SIZE say.  An explicit SCTC_SHARED_DEVICE in the environment wins.
+    Returns (shared, ids).  One line per rank on stderr."""
+    import socket
+    import sys
+    import torch.distributed as dist
+    L = lib()
+    if my_id is None:
+        my_id = (socket.gethostname(), device_bus_id())
+    rank, ids = 0, [tuple(my_id)]
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        rank = dist.get_rank(group)
+        gathered = [None] * dist.get_world_size(group)
+        dist.all_gather_object(gathered, tuple(my_id), group=group)
+        ids = [tuple(x) for x in gathered]
+    if "SCTC_SHARED_DEVICE" in os.environ:
+        shared, why = bool(L.sctc_shared_device()), "SCTC_SHARED_DEVICE in the environment"
+    else:
+        shared, why = shared_device_from_ids(ids, rank), "bus ids of %d rank(s)" % len(ids)
+        L.sctc_set_shared_device(1 if shared else 0)
+    if log:
+        sys.stderr.write("sctc: rank %d -> %s %s, shared=%d (%s)\n"
+                         % (rank, my_id[0], my_id[1], int(shared), why))
+        sys.stderr.flush()
+    return shared, ids
 
 
 def lib():
@@ -152,11 +201,11 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if L.sctc_abi_version() != 3:
+        if L.sctc_abi_version() != 4:
             raise ImportError("libsctc_hip.so ABI version mismatch")
         _lib = L
-        if "SCTC_SHARED_DEVICE" not in os.environ and _ranks_share_a_device():
-            L.sctc_set_shared_device(1)
+        if "SCTC_SHARED_DEVICE" not in os.environ and _ranks_probably_share_a_device():
+            L.sctc_set_shared_device(1)        # provisional; resolve_shared_device() decides by bus id
     return _lib
 
 

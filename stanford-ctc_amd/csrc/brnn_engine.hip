@@ -845,6 +845,7 @@ static int run_cost_and_grad(sctc_brnn* h, const sctc_minibatch* mb, int flags, 
     if (h->profiling) memset(h->phase_ms, 0, sizeof(h->phase_ms));
     h->tev_n = 0;
     SCTC_TRY(make_plan(h, mb, true, s));
+    if (h->TL > 0) SCTC_TRY(recurrent_clear_error(h->counters, s));   // sticky for the whole step
     SCTC_TRY(run_forward(h, mb, s, pt));
     SCTC_TRY(run_ctc(h, mb, s));
     pt.begin(SCTC_PHASE_OTHER);
@@ -907,6 +908,9 @@ int sctc_brnn_create(const sctc_brnn_config* cfg, float* params_dev, float* grad
     // padding columns of the CTC gradient are never written by the kernels: zero once
     hipError_t e = hipSuccess;
     if (cfg->train) e = hipMemset(h->dlogits, 0, sizeof(float) * h->maxF * LD(h->Ap));
+    // the error word and the step flags: an engine that never runs a recurrent launch (a stream lane
+    // without utterances, a net without a temporal layer) must not report what the allocator left here
+    if (e == hipSuccess) e = hipMemset(h->counters, 0, sizeof(unsigned) * REC_COUNTER_WORDS);
     if (e != hipSuccess) {
         delete h;
         return set_error(SCTC_ERR_HIP, "brnn_create: %s", hipGetErrorString(e));
@@ -1047,6 +1051,7 @@ static int forward_once(sctc_brnn_t h, const sctc_minibatch* mb, float* probs_de
     if (h->profiling) memset(h->phase_ms, 0, sizeof(h->phase_ms));
     h->tev_n = 0;
     SCTC_TRY(make_plan(h, mb, false, s));
+    if (h->TL > 0) SCTC_TRY(recurrent_clear_error(h->counters, s));
     SCTC_TRY(run_forward(h, mb, s, pt));
     // probs back in the caller's per-utterance order, brnnet.py:170-173
     SCTC_TRY(launch_scatter_rows(probs_dev, h->A, h->probs, LD(h->Ap), h->d_src_row, h->N, h->A, s));
@@ -1067,6 +1072,15 @@ int sctc_set_shared_device(int32_t on)
 }
 
 int sctc_shared_device(void) { return recurrent_shared_device_mode(); }
+
+int sctc_device_pci_bus_id(int32_t device, char* out, int32_t out_len)
+{
+    SCTC_CHECK_ARG(out && out_len >= 16, "device_pci_bus_id: buffer of >= 16 bytes needed");
+    int dev = device;
+    if (dev < 0) SCTC_HIP_TRY(hipGetDevice(&dev));
+    SCTC_HIP_TRY(hipDeviceGetPCIBusId(out, out_len, dev));
+    return SCTC_OK;
+}
 
 int sctc_brnn_recurrent_path(sctc_brnn_t h, int32_t* forward_path, int32_t* bptt_path, int32_t* retries)
 {

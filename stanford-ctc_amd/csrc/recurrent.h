@@ -33,13 +33,15 @@ struct RecArgs {
     float* xbuf;
     const int32_t* xbase;   // device [Tmax]
     int32_t n_xrows;
-    unsigned* counters;     // [REC_COUNTER_WORDS]: error word at [2], per-producer step flags from [4]
+    unsigned* counters;     // [REC_COUNTER_WORDS]: sticky error word at [2], per-producer step flags from [32]
     int32_t sync_mode;      // 0: plain exchange stores + agent-scope release fence before the flag
                             // 1: write-through (sc1) exchange stores, no fence
     int32_t poll_delay;     // s_sleep units (64 cycles) before the first poll of a step; < 0: pick by layer size
     int32_t variant;        // 0: pick automatically; 1: force the one-workgroup-per-CU kernel;
                             // 2: two-chain kernel with the linear (not XCD-grouped) block map;
-                            // 3: force the non-persistent per-step fallback
+                            // 3: force the non-persistent per-step fallback;
+                            // 4: two workgroups per CU for 17..32 utterances (round 1-3 kernel);
+                            // 8..23: both chains in one 8-wave workgroup, mode = variant - 8
     unsigned* debug;        // nullable: s_memtime stamps [2 wgs][16 steps][8] for steps 64..79
     int32_t b_off;          // rank of this launch's first utterance in the packed minibatch (minibatches of
                             // more than 128 utterances run as several launches; T_b already points at it)
@@ -68,6 +70,8 @@ static constexpr int REC_PATH_PERSISTENT = 1;          // one whole-device persi
 static constexpr int REC_PATH_PERSISTENT_LEASED = 2;   // the same under the inter-process device lease
 static constexpr int REC_PATH_FALLBACK = 3;            // one launch per time step (no spinning)
 int launch_recurrent(const RecArgs& a, hipStream_t stream, int* path = nullptr);
+// clears the sticky error word (counters[2]): once per step, before its first recurrent launch
+int recurrent_clear_error(unsigned* counters, hipStream_t stream);
 // shared-device mode: persistent launches take an inter-process lease (flock on a per-device file)
 // and run synchronously.  Initial value: SCTC_SHARED_DEVICE in the environment.
 int recurrent_shared_device_mode();

@@ -113,6 +113,12 @@ class DataParallel(object):
         self.n_valid = 0
         self.cost_sum = 0.0
         self.regcost = 0.0
+        # which ranks sit on which physical GPU: the ranks exchange (hostname, PCI bus id) -- two on
+        # one GPU must take the device lease around their persistent recurrent launches, eight on eight
+        # GPUs must NOT (it would drain the stream around every launch and serialise the overlapped
+        # all-reduce), whatever HIP_VISIBLE_DEVICES / LOCAL_WORLD_SIZE look like
+        import _sctc
+        self.shared_device, self.device_ids = _sctc.resolve_shared_device(group)
 
     def allreduce_gradients(self, n_valid_local, cost_sum_local=0.0, regcost_local=None):
         """after net.costAndGradBatch on every rank: sums gradients, utterance counts and costs

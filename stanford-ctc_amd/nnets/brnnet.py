@@ -348,9 +348,11 @@ class NNet:
                                                  ctypes.c_void_p(ln["stream"].cuda_stream))
             _sctc.check(rc, "costAndGrad")
         for k, ln in enumerate(lanes):
-            _sctc.check(L.sctc_brnn_check(ln["h"], ctypes.c_void_p(ln["stream"].cuda_stream)), "costAndGrad")
             cur.wait_stream(ln["stream"])
-            if k > 0 and used[k]:                      # lane 0 wrote the model's gradient stack itself
+            if not used[k]:                            # fewer utterances than lanes: this engine ran nothing
+                continue
+            _sctc.check(L.sctc_brnn_check(ln["h"], ctypes.c_void_p(ln["stream"].cuda_stream)), "costAndGrad")
+            if k > 0:                                  # lane 0 wrote the model's gradient stack itself
                 _sctc.check(L.sctc_axpy(self._grads.data_ptr(), ln["grads"].data_ptr(), 1.0,
                                         self._grads.numel(), _sctc.current_stream_ptr()), "costAndGrad")
         if self.reg > 0:

@@ -54,7 +54,7 @@ def run(n_cases=40, seed=0):
         labs = [rs.randint(0, A, size=max(1, T // 6)).astype(np.int32) for T in Ts]
         def both(data_list):
             res = []
-            for variant in ("0", "1"):
+            for variant in (os.environ.get("SCTC_FUZZ_VARIANT", "0"), "1"):   # SCTC_FUZZ_VARIANT: the kernel under test (default: the automatic choice)
                 os.environ["SCTC_REC_VARIANT"] = variant
                 net = brnnet.NNet(D, A, H, NL, Tmax, temporalLayer=TL, maxUtts=B, reg=reg)
                 net.maxAct = max_act

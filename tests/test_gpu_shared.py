@@ -274,6 +274,34 @@ def test_one_utterance_per_stream(mods, n_streams):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("B,n_streams", [(3, 2), (1, 3)])
+def test_one_utterance_per_stream_fewer_utterances_than_lanes(mods, B, n_streams):
+    """B < 2 x n_streams leaves engines that never ran a step; their error word used to
+    be whatever the allocator had left in the workspace -> a spurious SCTC_ERR_TIMEOUT that also
+    switched shared-device mode on for the whole process.  Now: counters zeroed at creation, unused
+    lanes not checked."""
+    sctc, brnnet, obrnn, torch = mods
+    D, A, H, NL, TL = 24, 12, 512, 3, 2
+    rs = np.random.RandomState(77 + B)
+    Ts = [int(t) for t in rs.randint(6, 20, size=B)]
+    params, datas, labs = _problem(obrnn, 23, D, A, H, NL, TL, Ts)
+    with np.errstate(all="ignore"):
+        costs_ref, g_ref, skips_ref, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+    L = sctc.lib()
+    before = L.sctc_shared_device()
+    net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=max(B, 2))
+    # poison what a fresh allocation hands out, so that an un-zeroed counter block is not zero by luck
+    junk = torch.full((64 << 20,), -1, dtype=torch.int32, device="cuda")
+    del junk
+    for _ in range(2):
+        costs, _, skips = net.costAndGradStreams(datas, labs, n_streams=n_streams)
+        np.testing.assert_array_equal(skips, skips_ref)
+        np.testing.assert_allclose(costs[~skips_ref], costs_ref[~skips_ref], rtol=1e-4)
+        check_grads(net, g_ref, NL)
+    assert L.sctc_shared_device() == before
+    assert net.recurrentPath()[2] == 0          # no step was re-run
+
+
 def test_one_utterance_per_stream_full_width(mods):
     """the same at H = 1824 (the 228-workgroup small-batch grids of two streams side by side on the
     256 CUs), against one utterance per call"""
