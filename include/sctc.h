@@ -48,6 +48,9 @@ extern "C" {
 #define SCTC_BF16 3
 #define SCTC_BF16X3 4 /* fp32 operands split exactly into three bfloat16 terms (x = x1 + x2 + x3), six cross
                          products on the bfloat16 matrix cores, fp32 accumulate: an fp32-accurate GEMM */
+#define SCTC_OPERANDS_16BIT 0x100 /* sctc_gemm_h16 only, OR-ed into SCTC_F16 / SCTC_BF16: A_dev and B_dev already
+                                     point at 16-bit elements of that type (lda / ldb count them) -- the shadow
+                                     copies a producer wrote -- instead of fp32 values to be rounded */
 
 /* ---- library ---------------------------------------------------------- */
 
@@ -276,7 +279,10 @@ int sctc_gemm_f32(const float* A_dev, int64_t lda, int32_t a_kcontig, const floa
  * SCTC_BF16, round-to-nearest-even) on their way to the matrix cores and fp32 accumulation
  * (v_mfma_f32_32x32x16_f16 / _bf16): the GEMM of the "fp16 activations" configuration
  * (BASELINE configs[4]).  Operands and result stay fp32 in memory.
- * operand_dtype = SCTC_BF16X3: no rounding -- the three-term split described at sctc_brnn_config. */
+ * operand_dtype = SCTC_BF16X3: no rounding -- the three-term split described at sctc_brnn_config.
+ * operand_dtype | SCTC_OPERANDS_16BIT (SCTC_F16 / SCTC_BF16 only): the operands are 16-bit in memory already
+ * (both in the SAME layout: a_kcontig == b_kcontig, lda / ldb multiples of 8 elements); large problems
+ * then run on the LDS-DMA staged kernel (csrc/gemm_g16.hip), the path the engine's GEMMs take. */
 int sctc_gemm_h16(const float* A_dev, int64_t lda, int32_t a_kcontig, const float* B_dev,
                   int64_t ldb, int32_t b_kcontig, float* C_dev, int64_t ldc, int32_t M, int32_t N,
                   int32_t K, const float* bias_dev, int32_t relu, int32_t operand_dtype,

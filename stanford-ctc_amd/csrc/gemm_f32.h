@@ -63,6 +63,9 @@ int launch_gemm_f32(GemmArgs a, hipStream_t stream);     // dispatches on a.prec
 // gemm_h16.hip
 int64_t gemm_h16_plan_splits(int M, int N, int K, int* splits, int prec);
 int launch_gemm_h16_tiles(const GemmArgs& a, hipStream_t stream);
+// gemm_g16.hip: 16-bit operands in memory, staged by LDS-DMA (256 x 256 tiles)
+bool gemm_g16_applies(const GemmArgs& a);
+int launch_gemm_g16(const GemmArgs& a, hipStream_t stream);
 // prec 3 (gemm_s3.hip)
 int64_t gemm_s3_plan_splits(int M, int N, int K, int* splits);
 int launch_gemm_s3(const GemmArgs& a, hipStream_t stream);

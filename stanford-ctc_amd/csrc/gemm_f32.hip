@@ -479,11 +479,13 @@ extern "C" int sctc_gemm_h16(const float* A_dev, int64_t lda, int32_t a_kcontig,
                              void* stream)
 {
     using namespace sctc;
-    SCTC_CHECK_ARG(operand_dtype == SCTC_F16 || operand_dtype == SCTC_BF16 || operand_dtype == SCTC_BF16X3,
-                   "gemm_h16: operand_dtype must be SCTC_F16, SCTC_BF16 or SCTC_BF16X3");
+    const int in16 = (operand_dtype & SCTC_OPERANDS_16BIT) ? 1 : 0;
+    operand_dtype &= ~SCTC_OPERANDS_16BIT;
+    SCTC_CHECK_ARG(operand_dtype == SCTC_F16 || operand_dtype == SCTC_BF16 || (operand_dtype == SCTC_BF16X3 && !in16),
+                   "gemm_h16: operand_dtype must be SCTC_F16, SCTC_BF16 (optionally | SCTC_OPERANDS_16BIT) or SCTC_BF16X3");
     return gemm_entry(A_dev, lda, a_kcontig, B_dev, ldb, b_kcontig, C_dev, ldc, M, N, K, bias_dev,
                       relu, workspace_dev, workspace_bytes, stream,
-                      operand_dtype == SCTC_F16 ? 1 : (operand_dtype == SCTC_BF16 ? 2 : 3));
+                      (operand_dtype == SCTC_F16 ? 1 : (operand_dtype == SCTC_BF16 ? 2 : 3)) | (in16 ? 0x100 : 0));
 }
 
 extern "C" int sctc_gemm_f32(const float* A_dev, int64_t lda, int32_t a_kcontig,
@@ -509,7 +511,9 @@ static int gemm_entry(const float* A_dev, int64_t lda, int32_t a_kcontig, const 
     g.B = B_dev; g.ldb = ldb; g.b_kcontig = b_kcontig;
     g.C = C_dev; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias_dev; g.relu = relu;
-    g.prec = prec;
+    g.prec = prec & 0xff;
+    g.in16 = (prec & 0x100) ? 1 : 0;
+    prec &= 0xff;
     int splits = 1;
     const int64_t need = gemm_plan_splits(M, N, K, &splits, prec);
     if (splits > 1 && workspace_dev && workspace_bytes >= (size_t)need * sizeof(float)) {

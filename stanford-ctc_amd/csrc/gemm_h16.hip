@@ -461,7 +461,8 @@ static int launch_h16(const GemmArgs& a, hipStream_t stream)
 int launch_gemm_h16_tiles(const GemmArgs& a, hipStream_t stream)
 {
     if (a.prec == 3) return launch_gemm_s3(a, stream);
-    return h16_pick_big(a.M, a.N) ? launch_h16<1>(a, stream) : launch_h16<0>(a, stream);
+    if (h16_pick_big(a.M, a.N)) return gemm_g16_applies(a) ? launch_gemm_g16(a, stream) : launch_h16<1>(a, stream);
+    return launch_h16<0>(a, stream);
 }
 
 }  // namespace sctc

@@ -177,3 +177,40 @@ def oracle_parallel(params, datas, labs, TL, max_act=20.0, want_grad=True, procs
             total["Wf"] += g["Wf"]
             total["Wb"] += g["Wb"]
     return costs, total, skips
+
+
+_VARIANT_CTX = None
+
+
+def _oracle_variant(k):
+    params, data, lab, TL, max_act, jobs = _VARIANT_CTX
+    from oracle import brnn as obrnn
+    job = jobs[k]
+    mixed = None if job.get("mixed_rec") is None else obrnn.Mixed(rec=job["mixed_rec"])
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=job_threads())
+    except Exception:
+        import contextlib
+        ctx = contextlib.nullcontext()
+    with ctx, np.errstate(all="ignore"):
+        c, g, s, _ = obrnn.cost_and_grad(params, np.asarray(data, dtype=np.float64), lab, TL, max_act,
+                                         mixed=mixed, masks=job.get("masks"))
+    return c, g, bool(s)
+
+
+def oracle_variants(params, data, lab, TL, jobs, max_act=20.0):
+    """ONE utterance through several variants of the float64 oracle at once, one forked process each:
+    jobs = [{"mixed_rec": None | False | True, "masks": None | device masks}, ...]
+    -> [(cost, grads, skip), ...].  The cfg-5 utterance (T = 8000, 7 x 2048) takes the host about a
+    minute per variant; plain + device-gated (or Mixed + exact) run side by side."""
+    global _VARIANT_CTX
+    import multiprocessing as mp
+    _VARIANT_CTX = (params, data, lab, TL, max_act, jobs)
+    try:
+        if len(jobs) == 1:
+            return [_oracle_variant(0)]
+        with mp.get_context("fork").Pool(len(jobs)) as pool:
+            return pool.map(_oracle_variant, range(len(jobs)), chunksize=1)
+    finally:
+        _VARIANT_CTX = None

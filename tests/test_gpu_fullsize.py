@@ -24,11 +24,11 @@ The oracle runs in forked host processes (tests/helpers.oracle_parallel)."""
 import numpy as np
 import pytest
 
-from tests.helpers import oracle_parallel
+from tests.helpers import oracle_parallel, oracle_variants
 from tests.test_gpu_brnn import make_net, rel
 
 TOL = {"W1": 3e-3}          # (b) plain oracle; every other tensor: TOL_DEFAULT
-TOL_DEFAULT = 3e-4
+TOL_DEFAULT = 1.5e-4      # observed <= 9.8e-5 over rounds 2-3 (tightened from 3e-4)
 TOL_MASKED = 1e-4           # (a) oracle with the device's gate decisions: every tensor
 
 
@@ -206,10 +206,29 @@ def test_cfg5_long_utterances(mods):
     c1, _, s1 = net.costAndGradBatch([datas[2]], [labs[2]])
     g1 = tensors(net, NL)
     assert not s1.any()
-    c_ref, _, s_ref = oracle_parallel(params, [datas[2]], [labs[2]], TL, want_grad=False, procs=1)
-    assert not s_ref.any()
-    print("cfg5 B=1 cost %.4f oracle %.4f rel %.2e" % (c1[0], c_ref[0], abs(c1[0] - c_ref[0]) / c_ref[0]))
-    assert c1[0] == pytest.approx(c_ref[0], rel=1e-4)
+    # the reference's own parity check (debug-utils/checkgrads.py:20-40) compares GRADIENTS device vs
+    # CPU: one T=8000 utterance, every tensor, against the plain oracle and against the oracle whose
+    # backward pass uses the device's gate decisions (both variants in forked host processes)
+    masks = device_masks(net, NL, TL, H, 1, T)(0)
+    (c_ref, g_ref, s_ref), (_, g_msk, _) = oracle_variants(params, datas[2], labs[2], TL,
+                                                           [{"masks": None}, {"masks": masks}])
+    del masks
+    assert not s_ref
+    print("cfg5 B=1 cost %.4f oracle %.4f rel %.2e" % (c1[0], c_ref, abs(c1[0] - c_ref) / c_ref))
+    assert c1[0] == pytest.approx(c_ref, rel=1e-4)
+    want = oracle_tensors(g_ref, NL)
+    worst = {k: rel(g1[k], want[k]) for k in want}
+    print("cfg5 B=1 gradient rel-norm errors vs the plain oracle:", {k: "%.1e" % v for k, v in worst.items()})
+    want_m = oracle_tensors(g_msk, NL)
+    worst_m = {k: rel(g1[k], want_m[k]) for k in want_m}
+    print("cfg5 B=1 gradient rel-norm errors, oracle with the device's gates:",
+          {k: "%.1e" % v for k, v in worst_m.items()})
+    assert all(v < TOL_MASKED for v in worst_m.values()), worst_m
+    # plain oracle: tied gate decisions (float32 vs float64) put whole deltas on one side only; with
+    # 131 M gated units per utterance a handful of ties is expected -- 3e-4 here (dW1 3e-3), see the
+    # module docstring and test_cfg4_input_layer_gradient_error_decomposed
+    assert all(v < TOL.get(k, 3e-4) for k, v in worst.items()), worst
+    del g_ref, g_msk, want, want_m
     c8, _, s8 = net.costAndGradBatch(datas, labs)
     g8 = tensors(net, NL)
     assert not s8.any()
