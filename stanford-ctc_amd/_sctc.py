@@ -117,28 +117,6 @@ class SctcError(RuntimeError):
     pass
 
 
-_VISIBILITY_VARS = ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL")
-
-
-def _ranks_probably_share_a_device():
-    """Provisional guess at load time, before any process group exists: torch.distributed.run put
-    more local ranks on this node than there are visible GPUs AND no launcher restricted this
-    rank's view of the devices (with HIP_VISIBLE_DEVICES=$LOCAL_RANK every rank of an 8-GPU node
-    sees ONE device, and counting would call that sharing).  The authoritative decision is
-    resolve_shared_device(): the ranks exchange the PCI bus ids of their devices."""
-    try:
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
-    except ValueError:
-        return False
-    if local_world <= 1 or any(v in os.environ for v in _VISIBILITY_VARS):
-        return False
-    try:
-        import torch
-        return local_world > max(1, torch.cuda.device_count())
-    except Exception:
-        return False
-
-
 def device_bus_id(device=-1):
     """PCI bus id of HIP device `device` (-1: current): the physical identity of the GPU"""
     buf = ctypes.create_string_buffer(64)
@@ -204,8 +182,9 @@ def lib():
         if L.sctc_abi_version() != 4:
             raise ImportError("libsctc_hip.so ABI version mismatch")
         _lib = L
-        if "SCTC_SHARED_DEVICE" not in os.environ and _ranks_probably_share_a_device():
-            L.sctc_set_shared_device(1)        # provisional; resolve_shared_device() decides by bus id
+        # shared-device mode is not guessed here: the library finds out by itself how many processes use
+        # the physical GPU (marker files keyed by PCI bus id, csrc/recurrent.hip), and ranks of a process
+        # group exchange their bus ids (resolve_shared_device, called by dist_sgd.DataParallel)
     return _lib
 
 

@@ -495,6 +495,10 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
                 g.C16a = h->act16f[i];
                 g.C16b = h->cfg.train ? h->act16b[i] : nullptr;
                 g.ldc16 = LD(outp);
+                // "fp16 activations": a ReLU layer's output is read by the next layer's GEMM (float16),
+                // by this layer's weight gradient (bfloat16) and by the ReLU mask of the delta GEMM (its
+                // sign) -- nobody needs the fp32 copy, and not writing it halves the GEMM's stores
+                g.skip_c32 = 1;
             }
         }
         maybe_split(h, g);
@@ -558,6 +562,9 @@ static int check_recurrent_error(sctc_brnn* h, hipStream_t s)
     if (e != 0) {
         // whoever else holds compute units of this device will still be there on the next launch:
         // from now on every persistent launch of this process takes the inter-process lease
+        if (!recurrent_shared_device_mode())
+            fprintf(stderr, "sctc: a persistent recurrent launch timed out (its workgroups were not co-resident): "
+                            "shared-device mode is on for the rest of this process\n");
         recurrent_set_shared_device_mode(1);
         return set_error(SCTC_ERR_TIMEOUT, "recurrent kernel: a persistent launch gave up waiting for "
                          "its peers (the %d workgroups of a pass were not co-resident: device shared "
@@ -732,6 +739,15 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
                 g.b_kcontig = 1;
                 g.C16b = bufs16[which];
                 g.ldc16 = LD(inp);
+                if (i != h->TL) {
+                    // the layer's activations exist as 16-bit shadows only (run_forward): the mask is their
+                    // sign; and this delta is read by 16-bit GEMM operands only -- the BPTT recurrence, which
+                    // takes the fp32 delta as its additive term, follows the dgrad of layer TL alone
+                    g.mask = nullptr;
+                    g.mask16 = h->act16b[i];
+                    g.ldmask16 = LD(h->Hp);
+                    g.skip_c32 = 1;
+                }
             }
             maybe_split(h, g);
             SCTC_TRY(launch_gemm_f32(g, s));
@@ -1106,6 +1122,9 @@ int sctc_brnn_debug_buffer(sctc_brnn_t h, int32_t which, void** dev_ptr, int64_t
                            int64_t* ld)
 {
     SCTC_CHECK_ARG(h && dev_ptr && rows && cols && ld, "debug_buffer: null argument");
+    SCTC_CHECK_ARG(!(h->cfg.operand_dtype == SCTC_F16 && ((which >= 1 && which <= h->NL && which != h->TL) || which == 200)),
+                   "debug_buffer: in the fp16-operand configuration the ReLU layers' activations and the deltas "
+                   "between them exist as 16-bit shadows only (buffer %d has no fp32 copy)", which);
     const float* p = nullptr;
     int64_t c = h->Hp, l = LD(h->Hp);
     if (which >= 0 && which <= h->NL) {

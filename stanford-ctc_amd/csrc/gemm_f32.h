@@ -55,7 +55,18 @@ struct GemmArgs {
     uint16_t* C16a;
     uint16_t* C16b;
     int64_t ldc16;
+    // "fp16 activations" proper (round 4): skip_c32 != 0 -- the fp32 result is NOT stored, only the
+    // 16-bit shadow(s) are (a hidden layer's activations / a delta whose only readers are 16-bit
+    // GEMM operands); needs C16a or C16b and no accumulate.  mask16: the ReLU mask operand as a
+    // 16-bit matrix (float16 or bfloat16 bits, row stride ldmask16): keep where the value is > 0,
+    // i.e. sign bit clear and not zero -- rounding to 16 bit keeps sign and zero-ness (float16
+    // flushes |x| < 2^-25 to zero).  Exclusive with `mask`.
+    int32_t skip_c32;
+    const uint16_t* mask16;
+    int64_t ldmask16;
 };
+// the 16-bit value v (float16 or bfloat16 bits) is > 0
+__host__ __device__ inline bool gemm_pos16(unsigned v) { return (v & 0x8000u) == 0u && (v & 0x7fffu) != 0u; }
 
 // picks the split-K factor; returns the workspace floats needed (0 when splits == 1)
 int64_t gemm_plan_splits(int M, int N, int K, int* splits, int prec = 0);

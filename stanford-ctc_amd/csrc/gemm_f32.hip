@@ -64,6 +64,7 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& p, float v, int r
     if (p.bias) v += p.bias[col];
     if (p.relu) v = fmaxf(v, 0.f);
     if (p.mask) v = p.mask[(int64_t)row * p.ldmask + col] > 0.f ? v : 0.f;
+    if (p.mask16) v = gemm_pos16(p.mask16[(int64_t)row * p.ldmask16 + col]) ? v : 0.f;
     if (p.addend) v += p.add_scale * p.addend[(int64_t)row * p.ldadd + col];
     if (p.accumulate) v += p.C[(int64_t)row * p.ldc + col];
     return v;
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p)
         for (int z = 0; z < p.splits; ++z) v += p.splitk_ws[z * total + i];  // fixed order
         const int row = (int)(i / p.N), col = (int)(i % p.N);
         const float o = gemm_epilogue(p, v, row, col);
-        p.C[(int64_t)row * p.ldc + col] = o;
+        if (!p.skip_c32) p.C[(int64_t)row * p.ldc + col] = o;
         if (p.C16a) p.C16a[(int64_t)row * p.ldc16 + col] = __builtin_bit_cast(unsigned short, (_Float16)o);
         if (p.C16b) p.C16b[(int64_t)row * p.ldc16 + col] = __builtin_bit_cast(unsigned short, (__bf16)o);
     }
@@ -436,6 +437,9 @@ int launch_gemm_f32(GemmArgs a, hipStream_t stream)
     } else {
         SCTC_CHECK_ARG((!a.C16a && !a.C16b) || a.prec != 0, "gemm: 16-bit shadow outputs need prec != 0");
     }
+    SCTC_CHECK_ARG(!a.skip_c32 || ((a.C16a || a.C16b) && !a.accumulate && a.prec != 0),
+                   "gemm: skip_c32 needs a 16-bit shadow output, no accumulate and prec != 0");
+    SCTC_CHECK_ARG(!a.mask16 || (!a.mask && a.prec != 0 && a.ldmask16 % 4 == 0), "gemm: mask16 excludes mask, needs prec != 0");
     if (a.a_kcontig) SCTC_CHECK_ARG(a.K % 4 == 0, "gemm: K must be a multiple of 4 (A K-contig)");
     else SCTC_CHECK_ARG(a.M % 4 == 0, "gemm: M must be a multiple of 4 (A row-contig)");
     if (a.b_kcontig) SCTC_CHECK_ARG(a.K % 4 == 0, "gemm: K must be a multiple of 4 (B K-contig)");

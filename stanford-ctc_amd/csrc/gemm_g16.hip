@@ -31,6 +31,7 @@
 //     equals the row-major order, for square problems it cuts the memory-side traffic.
 // The fused bias gradient (column sums of a row-contiguous A, brnnet.py:200) is taken from the LDS
 // image by the blocks of the first N tile (fp32 sums of the 16-bit deltas, fixed order).
+#include <algorithm>
 #include <mutex>
 #include <set>
 #include <type_traits>
@@ -44,19 +45,124 @@ namespace sctc {
 typedef __attribute__((address_space(3))) void g16_lds_void;
 typedef __attribute__((address_space(1))) const void g16_gbl_void;
 typedef __attribute__((address_space(3))) b16x4 g16_lds_b16x4;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static __device__ __attribute__((aligned(16))) unsigned g16_zero[4];   // the source of out-of-range pieces
 
-static constexpr int G_BM = 256, G_BN = 256, G_BK = 64, G_NT = 512;
-static constexpr int G_OPB = G_BM * G_BK * 2;    // bytes per operand and buffer (32 KiB)
-static constexpr int G_BUFB = 2 * G_OPB;         // A + B
+static constexpr int G_BM = 256, G_BN = 256, G_BK = 32, G_NT = 512;
+static constexpr int G_NST = 4;                  // LDS stages: the loads of K tile t + 3 are issued while tile t computes
+static constexpr int G_OPB = G_BM * G_BK * 2;    // bytes per operand and stage (16 KiB)
+static constexpr int G_STB = 2 * G_OPB;          // A + B
 static constexpr int G_GR = 4;                   // tile rows per band of the tile walk
 // diagnostics builds (tools/build_variant.sh ... "-DSCTC_G16_ABLATE=n", tests/gpu_g16.py speed): bit 0 no MFMAs,
-// bit 1 no fragment reads, bit 2 no LDS-DMA after the first K tile, bit 3 no vmcnt wait / barrier per K tile
+// bit 1 no fragment reads, bit 2 no LDS-DMA after the prologue, bit 3 no vmcnt wait / barrier per K tile
 #ifndef SCTC_G16_ABLATE
 #define SCTC_G16_ABLATE 0
 #endif
 static constexpr int G_ABL = SCTC_G16_ABLATE;
+
+// Epilogue through LDS.  The accumulator layout (swapped MFMA operands) gives a lane one output ROW
+// and 4 consecutive columns per register quad: stored directly (gemm_h16_dev.h, h16_epilogue), one store
+// instruction writes 32 bytes into each of 32 different rows.  Measured with the epilogue removed
+// (ablation build): 0.27 of 0.63 ms at 64000 x 2048 x 2048 and 0.30 of 0.93 ms at 8192^3 went into those
+// stores -- per instruction 32 partial lines whose addresses differ by the row stride (8 / 32 KiB).
+// Here every wave first parks its 64 x 64 half of its sub-tile in its own LDS region (row stride 272 B:
+// the ds_write_b128 of 8 consecutive rows cover 32 banks), reads it back row by row -- lane l: row
+// it * 4 + l / 16, columns 4 (l % 16) .. + 3 -- and a store instruction writes 4 rows x 256 contiguous
+// bytes; bias, mask, addend and accumulate operands are fetched in the same row-contiguous pattern.
+static constexpr int G_ERS = 272;                    // bytes per row of the staging image
+static constexpr int G_EPI_LDS = 8 * 64 * G_ERS;     // 8 waves x 64 rows
+
+template <int TM, int TN>
+__device__ __forceinline__ void g16_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
+                                             int wn, int lane, unsigned char* lds_wave)
+{
+    static_assert(TM == 4 && TN == 2, "wave sub-tile 128 x 64");
+    const int M = p.M, N = p.N;
+    const bool partial = p.splits > 1;
+    float* out = partial ? p.splitk_ws + (int64_t)blockIdx.y * M * N : p.C;
+    const int64_t ldo = partial ? N : p.ldc;
+    const bool has_mask = !partial && p.mask, has_add = !partial && p.addend;
+    const bool has_mask16 = !partial && p.mask16, skip32 = !partial && p.skip_c32;
+    const bool has_acc = !partial && p.accumulate;
+    const bool has_bias = !partial && p.bias;
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    const bool vec = (N % 4 == 0) && (ldo % 4 == 0) && al16(out) &&
+                     (!has_mask || (p.ldmask % 4 == 0 && al16(p.mask))) &&
+                     (!has_mask16 || (p.ldmask16 % 4 == 0 && ((uintptr_t)p.mask16 & 7) == 0)) &&
+                     (!has_add || (p.ldadd % 4 == 0 && al16(p.addend))) &&
+                     (!has_acc || (p.ldc % 4 == 0 && al16(p.C))) && (!has_bias || al16(p.bias)) &&
+                     (partial || ((!p.C16a || (p.ldc16 % 4 == 0 && ((uintptr_t)p.C16a & 7) == 0)) &&
+                                  (!p.C16b || (p.ldc16 % 4 == 0 && ((uintptr_t)p.C16b & 7) == 0))));
+    if (!vec) {                                      // block-uniform: odd shapes / alignments take the direct path
+        h16_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane);
+        return;
+    }
+    const int wrow = lane & 31, wcol = 4 * (lane >> 5);          // accumulator layout
+    const int rrow = lane >> 4, rcol = 4 * (lane & 15);          // read-back layout
+    const int gcol = n0 + wn * 64 + rcol;
+    const bool col_ok = gcol < N;                                 // N % 4 == 0
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_bias && col_ok) bias4 = *reinterpret_cast<const float4*>(p.bias + gcol);
+    static_for<2>([&](auto HALF) {
+        constexpr int half = decltype(HALF)::value;
+        static_for<2 * TN * 4>([&](auto Q) {
+            constexpr int i2 = decltype(Q)::value / (TN * 4), j = (decltype(Q)::value / 4) % TN, g = decltype(Q)::value % 4;
+            constexpr int i = 2 * half + i2;
+            const f32x4 v = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(lds_wave + (i2 * 32 + wrow) * G_ERS + (j * 32 + 8 * g + wcol) * 4) = v;
+        });
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 4 + rrow;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(lds_wave + row * G_ERS + rcol * 4);
+            float v[4] = {t[0], t[1], t[2], t[3]};
+            const int grow = m0 + wm * 128 + half * 64 + row;
+            const int64_t rc = min(grow, M - 1);
+            if (!partial) {
+                if (has_bias) { v[0] += bias4.x; v[1] += bias4.y; v[2] += bias4.z; v[3] += bias4.w; }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (col_ok) {
+                    if (has_mask) {
+                        const float4 m = *reinterpret_cast<const float4*>(p.mask + rc * p.ldmask + gcol);
+                        v[0] = m.x > 0.f ? v[0] : 0.f; v[1] = m.y > 0.f ? v[1] : 0.f;
+                        v[2] = m.z > 0.f ? v[2] : 0.f; v[3] = m.w > 0.f ? v[3] : 0.f;
+                    }
+                    if (has_mask16) {
+                        const u32x2 m = *reinterpret_cast<const u32x2*>(p.mask16 + rc * p.ldmask16 + gcol);
+                        v[0] = gemm_pos16(m[0] & 0xffffu) ? v[0] : 0.f; v[1] = gemm_pos16(m[0] >> 16) ? v[1] : 0.f;
+                        v[2] = gemm_pos16(m[1] & 0xffffu) ? v[2] : 0.f; v[3] = gemm_pos16(m[1] >> 16) ? v[3] : 0.f;
+                    }
+                    if (has_add) {
+                        const float4 a = *reinterpret_cast<const float4*>(p.addend + rc * p.ldadd + gcol);
+                        v[0] += p.add_scale * a.x; v[1] += p.add_scale * a.y;
+                        v[2] += p.add_scale * a.z; v[3] += p.add_scale * a.w;
+                    }
+                    if (has_acc) {
+                        const float4 c = *reinterpret_cast<const float4*>(p.C + rc * p.ldc + gcol);
+                        v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
+                    }
+                }
+            }
+            if (grow < M && col_ok && (!(G_ABL & 128) || (it & 3) == 0)) {      // (bit 7: a quarter of the rows stored)
+                if (!skip32) *reinterpret_cast<float4*>(out + (int64_t)grow * ldo + gcol) = make_float4(v[0], v[1], v[2], v[3]);
+                if (!partial) {
+                    if (p.C16a) {
+                        const h16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                        *reinterpret_cast<h16x4*>(p.C16a + (int64_t)grow * p.ldc16 + gcol) = h;
+                    }
+                    if (p.C16b) {
+                        const b16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        *reinterpret_cast<b16x4*>(p.C16b + (int64_t)grow * p.ldc16 + gcol) = h;
+                    }
+                }
+            }
+        }
+    });
+}
 
 template <bool KC, bool BF>
 __global__ __launch_bounds__(G_NT, 2) void gemm_g16_kernel(GemmArgs p)
@@ -85,9 +191,17 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_g16_kernel(GemmArgs p)
     const int per = (ktiles + p.splits - 1) / p.splits;
     const int kt_beg = blockIdx.y * per;
     const int kt_end = min(ktiles, kt_beg + per);
+    const int k_end = min(K, kt_end * G_BK);      // pieces at k >= k_end come from the block of zeros
     const unsigned short* A16 = reinterpret_cast<const unsigned short*>(p.A);
     const unsigned short* B16 = reinterpret_cast<const unsigned short*>(p.B);
 
+#ifdef SCTC_G16_SKEW
+    // diagnostics: the first round of blocks starts skewed by (position in the XCD) x SCTC_G16_SKEW x 0.64 us
+    if (blockIdx.x < 256 && p.splits == 1) {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)((blockIdx.x >> 3) & 31) * SCTC_G16_SKEW * 64ull) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     f32x16 acc[TM][TN];
     static_for<TM * TN>([&](auto IJ) {
 #pragma unroll
@@ -98,68 +212,68 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_g16_kernel(GemmArgs p)
 
     if (kt_beg < kt_end) {
         const unsigned short* zsrc = reinterpret_cast<const unsigned short*>(g16_zero);
-        // ---- staging: 4 pieces of 16 B per thread, operand and K tile; LDS position of piece
+        // ---- staging: 2 pieces of 16 B per thread, operand and K tile; LDS position of piece
         // (round q, thread t) = (q * 512 + t) * 16, i.e. wave-uniform base + lane * 16
-        const unsigned short* srcA[4];
-        const unsigned short* srcB[4];
-        bool okA[4], okB[4];
-        int kpiece;      // KC: the thread's k offset inside a tile (elements); !KC: unused
-        int krow[4];     // !KC: the k-row of round q
+        const unsigned short* srcA[2];
+        const unsigned short* srcB[2];
+        bool okA = true, okB = true;
+        int kpiece = 0;  // KC: the thread's k offset inside a tile (elements)
+        int krow[2];     // !KC: the k-row of round q
         if constexpr (KC) {
-            const int s = (tid & 7) ^ ((tid >> 4) & 7);            // source k-slot of LDS slot tid & 7
-            kpiece = 8 * s;
+            // image [row][4 x 16 B]: k-slot s of row r at slot s ^ ((r >> 2) & 3); LDS slot t & 3 of row
+            // q * 128 + (t >> 2) therefore takes source slot (t & 3) ^ ((t >> 4) & 3)
+            kpiece = (G_ABL & 16) ? 8 * (tid & 3) : 8 * ((tid & 3) ^ ((tid >> 4) & 3));   // (bit 4: linear source, wrong results)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = q * 64 + (tid >> 3);
+            for (int q = 0; q < 2; ++q) {
+                const int r = q * 128 + (tid >> 2);
                 srcA[q] = A16 + (int64_t)min(m0 + r, M - 1) * p.lda + kpiece;
                 srcB[q] = B16 + (int64_t)min(n0 + r, N - 1) * p.ldb + kpiece;
-                okA[q] = okB[q] = true;
                 krow[q] = 0;
             }
         } else {
-            kpiece = 0;
-            const int m8 = (tid & 31) ^ (((tid >> 5) & 3) << 2);   // source m-piece of LDS piece tid & 31
+            // image [k][32 x 16 B]: m-piece q8 of k-row k at piece q8 ^ ((k & 3) << 2)
+            const int m8 = (G_ABL & 16) ? (tid & 31) : (tid & 31) ^ (((tid >> 5) & 3) << 2);
+            okA = m0 + 8 * m8 < M;
+            okB = n0 + 8 * m8 < N;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 2; ++q) {
                 krow[q] = q * 16 + (tid >> 5);
-                okA[q] = m0 + 8 * m8 < M;
-                okB[q] = n0 + 8 * m8 < N;
                 srcA[q] = A16 + m0 + 8 * m8;
                 srcB[q] = B16 + n0 + 8 * m8;
             }
         }
-        // one round (q) of the next K tile's pieces: 1 KiB of A and 1 KiB of B per wave
-        auto stage_q = [&](int buf, int kt, int q) {
+        // all pieces of K tile kt -> stage kt % G_NST.  Branch-free: tiles past the end of this block's K
+        // range read the block of zeros (a branch around an LDS-DMA costs every later wait its count)
+        auto stage = [&](int kt) {
+            if ((G_ABL & 4) && kt >= kt_beg + G_NST - 1) return;
             const int k0 = kt * G_BK;
-            unsigned char* dst = gsm + buf * G_BUFB + wave * 1024 + q * 8192;
-            const unsigned short* a;
-            const unsigned short* b;
-            if constexpr (KC) {
-                const bool kin = k0 + kpiece < K;               // K % 8 == 0
-                a = kin ? srcA[q] + k0 : zsrc;
-                b = kin ? srcB[q] + k0 : zsrc;
-            } else {
-                const int k = k0 + krow[q];
-                const bool kin = k < K;
-                a = (kin && okA[q]) ? srcA[q] + (int64_t)k * p.lda : zsrc;
-                b = (kin && okB[q]) ? srcB[q] + (int64_t)k * p.ldb : zsrc;
-            }
-            if ((G_ABL & 4) && kt != kt_beg) return;
-            __builtin_amdgcn_global_load_lds((g16_gbl_void*)a, (g16_lds_void*)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((g16_gbl_void*)b, (g16_lds_void*)(dst + G_OPB), 16, 0, 0);
-        };
-        auto stage = [&](int buf, int kt) {
+            unsigned char* dst = gsm + ((kt - kt_beg) & (G_NST - 1)) * G_STB + wave * 1024;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) stage_q(buf, kt, q);
+            for (int q = 0; q < 2; ++q) {
+                const unsigned short* a;
+                const unsigned short* b;
+                if constexpr (KC) {
+                    const bool kin = k0 + kpiece < k_end;               // K % 8 == 0
+                    a = kin ? srcA[q] + k0 : zsrc;
+                    b = kin ? srcB[q] + k0 : zsrc;
+                } else {
+                    const int k = k0 + krow[q];
+                    const bool kin = k < k_end;
+                    a = (kin && okA) ? srcA[q] + (int64_t)k * p.lda : zsrc;
+                    b = (kin && okB) ? srcB[q] + (int64_t)k * p.ldb : zsrc;
+                }
+                __builtin_amdgcn_global_load_lds((g16_gbl_void*)a, (g16_lds_void*)(dst + q * 8192), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((g16_gbl_void*)b, (g16_lds_void*)(dst + G_OPB + q * 8192), 16, 0, 0);
+            }
         };
 
-        // ---- fragment addresses (bytes from the start of a buffer's A / B image)
+        // ---- fragment addresses (bytes from the start of a stage's A / B image)
         const int li = lane & 31, kg = lane >> 5;
         int fa, fb;
         if constexpr (KC) {
-            const int bx = (kg ^ ((li >> 1) & 7)) * 16;
-            fa = (wm * 128 + li) * 128 + bx;          // fragment (kk, i): (fa ^ (32 kk)) + i * 4096
-            fb = (wn * 64 + li) * 128 + bx;
+            const int bx = (kg ^ ((li >> 2) & 3)) * 16;
+            fa = (wm * 128 + li) * 64 + bx;           // fragment (kk, i): (fa ^ (32 kk)) + i * 2048
+            fb = (wn * 64 + li) * 64 + bx;
         } else {
             const int j4 = (lane & 15) >> 2, grp = (lane >> 4) & 1, mq = lane & 3;
             const int low = grp * 32 + (mq >> 1) * 16 + (mq & 1) * 8;
@@ -168,7 +282,7 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_g16_kernel(GemmArgs p)
         }
         auto frag = [&](const unsigned char* img, int base, int kk, int t) -> V8 {
             if constexpr (KC) {
-                return *reinterpret_cast<const V8*>(img + (base ^ (32 * kk)) + t * 4096);
+                return *reinterpret_cast<const V8*>(img + (base ^ (32 * kk)) + t * 2048);
             } else {
                 const unsigned char* q = img + (base ^ (64 * t)) + kk * 8192;
                 const b16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((g16_lds_b16x4*)q);
@@ -178,60 +292,34 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_g16_kernel(GemmArgs p)
                 return __builtin_bit_cast(V8, v);
             }
         };
-        // One K tile: 4 k-steps of 16.  The fragments of step kk + 1 are requested BEFORE the MFMAs of step
-        // kk issue (two register sets), and one round of the next tile's LDS-DMA goes out per step: with
-        // both waves of a SIMD leaving the tile's barrier together, a wave that waits for its own
-        // ds_reads in front of every MFMA group leaves the matrix pipe idle half of the time (first
-        // version of this kernel: 1.94 us per K tile against 1.0 of MFMA time).
         V8 af[2][TM], bf[2][TN];
-        auto load_frags = [&](int buf, int kk, int set) {
-            if ((G_ABL & 2) && !(buf == 0 && kk == 0 && set == 0)) return;
-            const unsigned char* ia = gsm + buf * G_BUFB;
+        auto load_frags = [&](int st, int kk, int set) {
+            if ((G_ABL & 2) && !(st == 0 && kk == 0 && set == 0)) return;
+            const unsigned char* ia = gsm + st * G_STB;
             const unsigned char* ib = ia + G_OPB;
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[set][j] = frag(ib, fb, kk, j);
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[set][i] = frag(ia, fa, kk, i);
         };
-        auto compute = [&](int buf, int kt_next, auto MORE) {      // MORE: compile-time (a branch around the
-#pragma unroll                                                       // LDS-DMA makes every lgkmcnt wait a full drain)
-            for (int kk = 0; kk < 4; ++kk) {
-                // first half of the step's MFMAs, THEN the next step's fragment reads and a round of
-                // LDS-DMA, then the second half: hipcc waits lgkmcnt(0) in front of the first MFMA that
-                // reads a fragment (never a counted wait once an LDS-DMA sits in the block), so the
-                // reads of step kk + 1 must not be in flight yet when step kk's first MFMA issues
-                __builtin_amdgcn_s_setprio(1);
-                static_for<TM * TN / 2>([&](auto IJ) {
-                    constexpr int i = decltype(IJ)::value / TN, j = decltype(IJ)::value % TN;
-                    const int st = (G_ABL & 2) ? 0 : (kk & 1);
-                    const V8 fb_ = bf[st][j], fa_ = af[st][i];
-                    if constexpr (G_ABL & 1) asm volatile("" :: "v"(fb_), "v"(fa_));
-                    else acc[i][j] = HT::mfma(fb_, fa_, acc[i][j]);
-                });
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (kk < 3) load_frags(buf, kk + 1, (kk + 1) & 1);
-                if constexpr (decltype(MORE)::value) stage_q(buf ^ 1, kt_next, kk);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-                static_for<TM * TN / 2>([&](auto IJ) {
-                    constexpr int i = TM / 2 + decltype(IJ)::value / TN, j = decltype(IJ)::value % TN;
-                    const int st = (G_ABL & 2) ? 0 : (kk & 1);
-                    const V8 fb_ = bf[st][j], fa_ = af[st][i];
-                    if constexpr (G_ABL & 1) asm volatile("" :: "v"(fb_), "v"(fa_));
-                    else acc[i][j] = HT::mfma(fb_, fa_, acc[i][j]);
-                });
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        auto mfmas = [&](int set, auto HALF) {
+            __builtin_amdgcn_s_setprio(1);
+            static_for<TM * TN / 2>([&](auto IJ) {
+                constexpr int i = decltype(HALF)::value * (TM / 2) + decltype(IJ)::value / TN, j = decltype(IJ)::value % TN;
+                const int st = (G_ABL & 2) ? 0 : set;
+                const V8 fb_ = bf[st][j], fa_ = af[st][i];
+                if constexpr (G_ABL & 1) asm volatile("" :: "v"(fb_), "v"(fa_));
+                else acc[i][j] = HT::mfma(fb_, fa_, acc[i][j]);
+            });
+            __builtin_amdgcn_s_setprio(0);
         };
-        // bias gradient: thread t sums columns 4 (t & 63) .. + 3 over the 8 k-rows 8 (t >> 6) .. + 7 of the tile
-        auto colsum = [&](int buf) {
-            const unsigned char* ia = gsm + buf * G_BUFB;
+        // bias gradient: thread t sums columns 4 (t & 63) .. + 3 over the 4 k-rows 4 (t >> 6) .. + 3 of the tile
+        auto colsum = [&](int st) {
+            const unsigned char* ia = gsm + st * G_STB;
             const int m8 = (tid & 63) >> 1, half = (tid & 1) * 8;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = 8 * (tid >> 6) + u;
+            for (int u = 0; u < 4; ++u) {
+                const int k = 4 * (tid >> 6) + u;
                 const u32x2 v = *reinterpret_cast<const u32x2*>(ia + k * 512 + ((m8 ^ ((k & 3) << 2)) * 16) + half);
                 csum[0] += HT::tofloat(v[0] & 0xffffu);
                 csum[1] += HT::tofloat(v[0] >> 16);
@@ -240,24 +328,56 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_g16_kernel(GemmArgs p)
             }
         };
 
-        stage(0, kt_beg);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int buf = 0;
-        for (int kt = kt_beg; kt + 1 < kt_end; ++kt) {
-            load_frags(buf, 0, 0);
-            compute(buf, kt + 1, std::true_type{});           // the next tile's pieces land in the other buffer
-            if (do_colsum) colsum(buf);
+        // ---- the K loop.
+        // (1) Three K tiles are in flight behind the one being multiplied: 4 LDS-DMA instructions per
+        //     thread and tile, so "my pieces of tile t + 1 have landed" is s_waitcnt vmcnt(8) -- counted,
+        //     never 0 -- and the barriers are RAW s_barrier (__syncthreads() would drain the queue: its
+        //     fence waits vmcnt(0) while an LDS-DMA is pending).
+        // (2) The two waves of a SIMD are STAGGERED by half an iteration.  An iteration is two barrier
+        //     intervals: "mem" (12 fragment reads of tile t, the 4 LDS-DMA pieces of tile t + 3, the
+        //     counted wait) and "mfma" (16 MFMAs).  Waves 4..7 (wave w + 4 shares a SIMD with wave w)
+        //     pass one extra barrier before the loop, waves 0..3 one after it, so that on every SIMD one
+        //     wave is in its mem interval while the other one feeds the matrix pipe.  Measured on the
+        //     unstaggered loop (ablation builds, 8192^3): LDS-DMA + barriers alone 0.79 ms, MFMAs +
+        //     fragment reads alone 0.74 ms, together 1.04 ms -- an LDS-DMA costs the issuing wave 60-180
+        //     cycles of issue time, and two waves that leave every barrier together spend them at the
+        //     same moment, with the matrix pipe idle.
+        //     Hazards (lead = one interval): a stage is refilled (tile t + 3 -> the stage of tile t - 1)
+        //     in mem(t); the other group read tile t - 1 in ITS mem(t - 1), which ended at a barrier
+        //     before that.  Tile t + 1 is read in mem(t + 1); both groups wait for their own pieces of it
+        //     at the end of their mem(t), and at least one barrier lies in between.
+        const bool late = wm == 1;                 // wave-uniform (scalar branch)
+        stage(kt_beg);
+        stage(kt_beg + 1);
+        stage(kt_beg + 2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (late) __builtin_amdgcn_s_barrier();
+        for (int kt = kt_beg; kt < kt_end; ++kt) {
+            const int st = (kt - kt_beg) & (G_NST - 1);
+            // -- mem interval
+            load_frags(st, 0, 0);
+            load_frags(st, 1, 1);
+            stage(kt + 3);                       // into the stage tile kt - 1 was multiplied from
+            if (do_colsum) colsum(st);
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(G_ABL & 8)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt + 1 are in LDS
-                __syncthreads();                                   // everybody's are, and buffer `buf` is free
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's pieces of tile kt + 1 are in LDS
+                __builtin_amdgcn_s_barrier();
             }
-            buf ^= 1;
+            __builtin_amdgcn_sched_barrier(0);
+            // -- mfma interval
+            mfmas(0, std::integral_constant<int, 0>{});
+            mfmas(0, std::integral_constant<int, 1>{});
+            mfmas(1, std::integral_constant<int, 0>{});
+            mfmas(1, std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(G_ABL & 8)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
         }
-        load_frags(buf, 0, 0);
-        compute(buf, 0, std::false_type{});
-        if (do_colsum) colsum(buf);
-        __syncthreads();                                       // (the bias-gradient reduction reuses the LDS)
+        if (!late) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the zero-sourced tail tiles
+        __syncthreads();                                           // (the bias-gradient reduction reuses the LDS)
     }
     if constexpr (!KC) {
         if (do_colsum) {     // block-uniform: [8 k-parts][256 columns] partial sums -> one sum per column, fixed order
@@ -276,7 +396,16 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_g16_kernel(GemmArgs p)
             }
         }
     }
-    h16_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, lane);
+    __syncthreads();      // the staging stages / the bias-gradient scratch are dead: the LDS is the epilogue's
+    if constexpr (!(G_ABL & 32)) g16_epilogue<TM, TN>(p, acc, (G_ABL & 64) ? 0 : m0, (G_ABL & 64) ? 0 : n0, wm, wn, lane, gsm + wave * (64 * G_ERS));   // (bit 6: every block stores to tile (0, 0))
+    else {     // (bit 5: no epilogue -- every accumulator stays live: summed, stored only for a value no data produces)
+        float t = 0.f;
+        static_for<TM * TN>([&](auto IJ) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[decltype(IJ)::value / TN][decltype(IJ)::value % TN][r];
+        });
+        if (t == 12345.678f) p.C[0] = t;
+    }   // (bit 5: no epilogue)
 }
 
 // ------------------------------------------------------------------ host side
@@ -296,7 +425,7 @@ int launch_gemm_g16(const GemmArgs& a, hipStream_t stream)
     const bool bf = a.prec == 2;
     void (*kern)(GemmArgs) = a.a_kcontig ? (bf ? gemm_g16_kernel<true, true> : gemm_g16_kernel<true, false>)
                                          : (bf ? gemm_g16_kernel<false, true> : gemm_g16_kernel<false, false>);
-    const size_t smem = 2 * G_BUFB;
+    const size_t smem = std::max<size_t>(G_NST * G_STB, G_EPI_LDS);
     {
         static std::mutex mu;
         static std::set<const void*> done;

@@ -120,11 +120,13 @@ __device__ __forceinline__ void h16_epilogue(const GemmArgs& p, f32x16 (&acc)[TM
     float* out = partial ? p.splitk_ws + (int64_t)blockIdx.y * M * N : p.C;
     const int64_t ldo = partial ? N : p.ldc;
     const bool has_mask = !partial && p.mask, has_add = !partial && p.addend;
+    const bool has_mask16 = !partial && p.mask16, skip32 = !partial && p.skip_c32;
     const bool has_acc = !partial && p.accumulate;
     const bool has_bias = !partial && p.bias;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     const bool vec = (N % 4 == 0) && (ldo % 4 == 0) && al16(out) &&
                      (!has_mask || (p.ldmask % 4 == 0 && al16(p.mask))) &&
+                     (!has_mask16 || (p.ldmask16 % 4 == 0 && ((uintptr_t)p.mask16 & 7) == 0)) &&
                      (!has_add || (p.ldadd % 4 == 0 && al16(p.addend))) &&
                      (!has_acc || (p.ldc % 4 == 0 && al16(p.C))) && (!has_bias || al16(p.bias)) &&
                      (partial || ((!p.C16a || (p.ldc16 % 4 == 0 && ((uintptr_t)p.C16a & 7) == 0)) &&
@@ -154,6 +156,11 @@ __device__ __forceinline__ void h16_epilogue(const GemmArgs& p, f32x16 (&acc)[TM
                         v[0] = m.x > 0.f ? v[0] : 0.f; v[1] = m.y > 0.f ? v[1] : 0.f;
                         v[2] = m.z > 0.f ? v[2] : 0.f; v[3] = m.w > 0.f ? v[3] : 0.f;
                     }
+                    if (has_mask16) {
+                        const u32x2 m = *reinterpret_cast<const u32x2*>(p.mask16 + rc * p.ldmask16 + colc);
+                        v[0] = gemm_pos16(m[0] & 0xffffu) ? v[0] : 0.f; v[1] = gemm_pos16(m[0] >> 16) ? v[1] : 0.f;
+                        v[2] = gemm_pos16(m[1] & 0xffffu) ? v[2] : 0.f; v[3] = gemm_pos16(m[1] >> 16) ? v[3] : 0.f;
+                    }
                     if (has_add) {
                         const float4 a = *reinterpret_cast<const float4*>(p.addend + rc * p.ldadd + colc);
                         v[0] += p.add_scale * a.x; v[1] += p.add_scale * a.y;
@@ -165,7 +172,7 @@ __device__ __forceinline__ void h16_epilogue(const GemmArgs& p, f32x16 (&acc)[TM
                     }
                 }
                 if (row < M && col < N) {
-                    *reinterpret_cast<float4*>(out + (int64_t)row * ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (!skip32) *reinterpret_cast<float4*>(out + (int64_t)row * ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
                     if (!partial) {
                         if (p.C16a) {
                             const h16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
@@ -187,12 +194,13 @@ __device__ __forceinline__ void h16_epilogue(const GemmArgs& p, f32x16 (&acc)[TM
                             if (has_bias) x += p.bias[c];
                             if (p.relu) x = fmaxf(x, 0.f);
                             if (has_mask) x = p.mask[(int64_t)row * p.ldmask + c] > 0.f ? x : 0.f;
+                            if (has_mask16) x = gemm_pos16(p.mask16[(int64_t)row * p.ldmask16 + c]) ? x : 0.f;
                             if (has_add) x += p.add_scale * p.addend[(int64_t)row * p.ldadd + c];
                             if (has_acc) x += p.C[(int64_t)row * p.ldc + c];
                             if (p.C16a) p.C16a[(int64_t)row * p.ldc16 + c] = __builtin_bit_cast(unsigned short, (_Float16)x);
                             if (p.C16b) p.C16b[(int64_t)row * p.ldc16 + c] = __builtin_bit_cast(unsigned short, (__bf16)x);
                         }
-                        out[(int64_t)row * ldo + c] = x;
+                        if (!skip32) out[(int64_t)row * ldo + c] = x;
                     }
                 }
             }

@@ -38,8 +38,11 @@
 #include <utility>
 #include <vector>
 
+#include <dirent.h>
 #include <errno.h>
 #include <fcntl.h>
+#include <string.h>
+#include <string>
 #include <sys/stat.h>
 #include <sys/file.h>
 #include <time.h>
@@ -1541,6 +1544,7 @@ static RecKernel pick_kernel(int nch_half)
 // on the fallback.
 
 static std::atomic<int> g_shared_mode{-1};   // -1: not yet read from the environment
+static std::atomic<int> g_shared_hard{0};    // SCTC_SHARED_DEVICE was in the environment: no automatic switch
 
 int recurrent_shared_device_mode()
 {
@@ -1548,6 +1552,7 @@ int recurrent_shared_device_mode()
     if (m < 0) {
         const char* e = getenv("SCTC_SHARED_DEVICE");
         m = (e && atoi(e) != 0) ? 1 : 0;
+        if (e) g_shared_hard.store(1, std::memory_order_relaxed);
         g_shared_mode.store(m, std::memory_order_relaxed);
     }
     return m;
@@ -1624,6 +1629,82 @@ struct LeaseGuard {
         g_lease.mu.unlock();
     }
 };
+
+// Who else uses this PHYSICAL device?  Every process that launches a persistent grid keeps an
+// exclusively flock'ed marker file /dev/shm/sctc_gpu_<pci-bus-id>.user.<pid> for its lifetime and touches it
+// at every persistent launch; counting the markers that are locked AND fresh tells how many processes are
+// launching persistent grids on the GPU right now,
+// whatever HIP_VISIBLE_DEVICES / LOCAL_WORLD_SIZE / device ordinals look like (round 3 guessed from
+// LOCAL_WORLD_SIZE > visible devices: wrong on an 8-GPU node whose launcher shows every rank one
+// device, and wrong the other way on a box that exports a global visibility mask).  More than one ->
+// shared-device mode switches itself on (one line on stderr).  Checked at persistent launches number
+// 1, 2, 4, ... 32 and every 32nd after that (a directory scan of /dev/shm, ~20 us) while the mode is
+// off; ranks that exchange their bus ids over a process group (dist_sgd.DataParallel) decide at once.
+static constexpr double USER_ACTIVE_S = 0.3;     // a marker untouched for this long belongs to an idle process (a trainer launches every few ms)
+struct DeviceUsers {
+    std::mutex mu;
+    std::map<int, std::pair<int, std::string>> mine;    // device -> (held marker fd, marker prefix)
+    std::map<int, unsigned> launches;
+    static bool held_by_somebody(const char* path)
+    {
+        const int fd = open(path, O_RDWR | O_CLOEXEC | O_NOFOLLOW);
+        if (fd < 0) return false;
+        struct stat st;
+        bool held = false;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+            if (flock(fd, LOCK_SH | LOCK_NB) != 0) {
+                // alive -- and ACTIVE: its owner touches the marker at every persistent launch; a process
+                // that merely still exists (a test driver waiting for its child, an idle notebook) is no
+                // reason to serialise launches
+                struct timespec now;
+                clock_gettime(CLOCK_REALTIME, &now);
+                held = errno == EWOULDBLOCK && (double)(now.tv_sec - st.st_mtim.tv_sec) + 1e-9 * (double)(now.tv_nsec - st.st_mtim.tv_nsec) < USER_ACTIVE_S;
+            } else { (void)unlink(path); (void)flock(fd, LOCK_UN); }      // stale: its owner is gone
+        }
+        close(fd);
+        return held;
+    }
+    // number of live processes (this one included) that registered for device `dev`; 0: no markers to be had
+    int count(int dev)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = mine.find(dev);
+        if (it == mine.end()) {
+            char bus[64] = "unknown";
+            (void)hipDeviceGetPCIBusId(bus, sizeof(bus), dev);
+            for (char* c = bus; *c; ++c)
+                if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+            std::string prefix = std::string("sctc_gpu_") + bus + ".user.";
+            const std::string path = "/dev/shm/" + prefix + std::to_string((long)getpid());
+            const mode_t um = umask(0);
+            int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
+            (void)umask(um);
+            if (fd >= 0 && flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); fd = -1; }
+            it = mine.emplace(dev, std::make_pair(fd, prefix)).first;
+        }
+        if (it->second.first < 0) return 0;
+        int n = 1;
+        const std::string own = it->second.second + std::to_string((long)getpid());
+        if (DIR* d = opendir("/dev/shm")) {
+            while (struct dirent* e = readdir(d)) {
+                if (strncmp(e->d_name, it->second.second.c_str(), it->second.second.size()) != 0) continue;
+                if (own == e->d_name) continue;
+                if (held_by_somebody((std::string("/dev/shm/") + e->d_name).c_str())) ++n;
+            }
+            closedir(d);
+        }
+        return n;
+    }
+    bool due(int dev)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = mine.find(dev);
+        if (it != mine.end() && it->second.first >= 0) (void)futimens(it->second.first, nullptr);   // "active now"
+        const unsigned k = ++launches[dev];
+        return k <= 32 ? (k & (k - 1)) == 0 : (k & 31) == 0;
+    }
+};
+DeviceUsers g_users;
 
 struct PersistentGate {   // in-process: persistent launches in flight, per device
     struct Entry { hipEvent_t ev; hipStream_t stream; int cus; };
@@ -1739,6 +1820,14 @@ static int launch_persistent(RecKernel k, int grid, size_t smem, int max_per_cu,
     const int need_cus = (grid + per_cu - 1) / per_cu;
     if (sentinel_bytes)   // sentinel-fill the exchange rows (both directions)
         SCTC_HIP_TRY(hipMemsetAsync(a.xbuf, 0xFF, sentinel_bytes, cx.stream));
+    if (!recurrent_shared_device_mode() && !g_shared_hard.load(std::memory_order_relaxed) && g_users.due(cx.dev)) {
+        const int n = g_users.count(cx.dev);
+        if (n > 1) {
+            recurrent_set_shared_device_mode(1);
+            fprintf(stderr, "sctc: %d processes run persistent kernels on this GPU: shared-device mode on "
+                            "(their launches take turns under /dev/shm/sctc_gpu_*.lock)\n", n);
+        }
+    }
     if (recurrent_shared_device_mode()) {
         // the lease is held exactly while the grid runs: nothing of ours queued in front of it,
         // nobody else's persistent grid next to it

@@ -95,13 +95,14 @@ def speed():
                                 (4096, 4096, 4096, 1, "square 4k"), (32000, 1824, 1824, 1, "cfg-3 fwd"),
                                 (1824, 1824, 32000, 0, "cfg-3 wgrad")):
         for dt, tt in ((_sctc.F16, torch.float16), (_sctc.BF16, torch.bfloat16)):
-            pad = lambda v: (v + 63) // 64 * 64
+            extra = int(os.environ.get("SCTC_G16_PAD", "0"))     # extra elements per row: leading dimensions off the powers of two
+            pad = lambda v: (v + 63) // 64 * 64 + extra
             A = torch.randn((M, pad(K)) if kc else (K, pad(M)), device="cuda").to(tt)
             B = torch.randn((N, pad(K)) if kc else (K, pad(N)), device="cuda").to(tt)
             C = torch.empty(M, pad(N), device="cuda")
             ms = timed(lambda: call(L, A, B, C, M, N, K, kc, dt, ws))
-            print("%s %-12s M=%5d N=%5d K=%5d %s: %.3f ms  %.0f TFLOP/s" %
-                  (tag, name, M, N, K, "f16 " if dt == _sctc.F16 else "bf16", ms, 2.0 * M * N * K / ms / 1e9), flush=True)
+            print("%s%s %-12s M=%5d N=%5d K=%5d %s: %.3f ms  %.0f TFLOP/s" %
+                  (tag, "+pad%d" % extra if extra else "", name, M, N, K, "f16 " if dt == _sctc.F16 else "bf16", ms, 2.0 * M * N * K / ms / 1e9), flush=True)
 
 
 if __name__ == "__main__":

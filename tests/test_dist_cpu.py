@@ -169,7 +169,7 @@ def _world8_worker(rank, world, port, out):
     import dist_sgd
     from oracle import brnn as obrnn
     L = _sctc.lib()
-    guess = _sctc._ranks_probably_share_a_device()
+    guess = bool(L.sctc_shared_device())      # what loading the library under this environment decided: nothing
     # (1) eight ranks, eight different GPUs (mocked bus ids): the device lease must stay OFF
     shared_a, ids_a = _sctc.resolve_shared_device(my_id=("node0", "0000:%02x:00.0" % (0x10 + rank)), log=False)
     mode_a = L.sctc_shared_device()
@@ -243,20 +243,19 @@ def test_gloo_world8_bus_ids_and_mean_gradient():
     np.testing.assert_allclose(res[0]["flat"] / n_valid, ref / n_valid, rtol=3e-5, atol=1e-6)
 
 
-def test_load_time_guess_only_without_visibility_masks(monkeypatch):
-    """the provisional guess lib() makes before any process group exists"""
+def test_no_guess_from_environment_counts(monkeypatch):
+    """loading the library never derives shared-device mode from LOCAL_WORLD_SIZE / visible-device
+    counts (round 3 did, and an 8-GPU node whose launcher shows each rank one device looked shared);
+    sharing is decided by physical identity: bus ids exchanged over the process group
+    (shared_device_from_ids) or the library's per-device marker files at launch time"""
     import _sctc
     import torch as _t
     monkeypatch.setattr(_t.cuda, "device_count", lambda: 1)
-    for v in _sctc._VISIBILITY_VARS:
-        monkeypatch.delenv(v, raising=False)
-    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
-    assert _sctc._ranks_probably_share_a_device()               # 2 ranks, 1 GPU, nobody masked anything
-    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
-    assert not _sctc._ranks_probably_share_a_device()
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
-    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "3")
-    assert not _sctc._ranks_probably_share_a_device()           # one visible device PER RANK is not sharing
+    monkeypatch.delenv("SCTC_SHARED_DEVICE", raising=False)
+    L = _sctc.lib()
+    L.sctc_set_shared_device(0)
+    assert L.sctc_shared_device() == 0
     assert _sctc.shared_device_from_ids([("a", "x"), ("a", "y"), ("a", "x")], 0)
     assert not _sctc.shared_device_from_ids([("a", "x"), ("a", "y"), ("a", "x")], 1)
     assert not _sctc.shared_device_from_ids([("a", "x"), ("b", "x")], 0)

@@ -181,7 +181,7 @@ def test_overlapped_allreduce_equals_flat_two_ranks(backend):
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert out["ok"] and out["world"] == 2 and out["buckets"] == 6
     if backend == "gloo":
-        assert out["shared_mode"] == 1        # LOCAL_WORLD_SIZE 2 > 1 visible device
+        assert out["shared_mode"] == 1        # two processes on one physical GPU: found through the marker files
 
 
 def _rccl_one_rank_env(port):
