@@ -265,11 +265,11 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
         for (int l = 0; l <= d.NL; ++l) {
             const int inp = l == 0 ? d.Dp : d.Hp, outp = l == d.NL ? d.Ap : d.Hp;
             int sp = 1;
-            sk = std::max<int64_t>(sk, gemm_plan_splits(outp, inp, (int)F, &sp, bwd_prec(c->operand_dtype)));
+            sk = std::max<int64_t>(sk, gemm_plan_splits(outp, inp, (int)F, &sp, bwd_prec(c->operand_dtype), c->operand_dtype == SCTC_F16));
         }
         if (d.TL > 0) {
             int sp = 1;
-            sk = std::max<int64_t>(sk, gemm_plan_splits(d.Hp, d.Hp, (int)F, &sp, bwd_prec(c->operand_dtype)));
+            sk = std::max<int64_t>(sk, gemm_plan_splits(d.Hp, d.Hp, (int)F, &sp, bwd_prec(c->operand_dtype), c->operand_dtype == SCTC_F16));
         }
     }
     // small minibatches (few row tiles) split K in the forward / delta-propagation GEMMs as well:
@@ -437,7 +437,7 @@ static GemmArgs gemm_defaults()
 static void maybe_split(const sctc_brnn* h, GemmArgs& g)
 {
     int sp = 1;
-    const int64_t need = gemm_plan_splits(g.M, g.N, g.K, &sp, g.prec);
+    const int64_t need = gemm_plan_splits(g.M, g.N, g.K, &sp, g.prec, g.in16);
     if (sp > 1 && h->splitk_ws && need <= h->splitk_floats) {
         g.splits = sp;
         g.splitk_ws = h->splitk_ws;
@@ -700,7 +700,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
                 g.B = reinterpret_cast<const float*>(h->act16b[i]);
             }
             int splits = 1;
-            gemm_plan_splits(g.M, g.N, g.K, &splits, g.prec);
+            gemm_plan_splits(g.M, g.N, g.K, &splits, g.prec, g.in16);
             g.splits = splits;
             SCTC_TRY(launch_gemm_f32(g, s));
             // The weight gradients of the layers above the temporal layer (loop indices i >= TL: W_{TL+1}
@@ -834,7 +834,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
                     g.B = reinterpret_cast<const float*>(b16);
                 }
                 int splits = 1;
-                gemm_plan_splits(g.M, g.N, std::max(g.K, 1), &splits, g.prec);
+                gemm_plan_splits(g.M, g.N, std::max(g.K, 1), &splits, g.prec, g.in16 && !g.idx_a);
                 g.splits = splits;
                 SCTC_TRY(launch_gemm_f32(g, s));
                 SCTC_HIP_TRY(hipEventRecord(h->grad_ev[k == 0 ? wf_index(h) : wb_index(h)], s));

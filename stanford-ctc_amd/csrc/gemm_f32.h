@@ -69,13 +69,14 @@ struct GemmArgs {
 __host__ __device__ inline bool gemm_pos16(unsigned v) { return (v & 0x8000u) == 0u && (v & 0x7fffu) != 0u; }
 
 // picks the split-K factor; returns the workspace floats needed (0 when splits == 1)
-int64_t gemm_plan_splits(int M, int N, int K, int* splits, int prec = 0);
+int64_t gemm_plan_splits(int M, int N, int K, int* splits, int prec = 0, int in16 = 0);   // in16: operands 16-bit in memory, same layout
 int launch_gemm_f32(GemmArgs a, hipStream_t stream);     // dispatches on a.prec
 // gemm_h16.hip
-int64_t gemm_h16_plan_splits(int M, int N, int K, int* splits, int prec);
+int64_t gemm_h16_plan_splits(int M, int N, int K, int* splits, int prec, int in16);
 int launch_gemm_h16_tiles(const GemmArgs& a, hipStream_t stream);
 // gemm_g16.hip: 16-bit operands in memory, staged by LDS-DMA (256 x 256 tiles)
 bool gemm_g16_applies(const GemmArgs& a);
+bool gemm_g16_enabled();
 int launch_gemm_g16(const GemmArgs& a, hipStream_t stream);
 // prec 3 (gemm_s3.hip)
 int64_t gemm_s3_plan_splits(int M, int N, int K, int* splits);

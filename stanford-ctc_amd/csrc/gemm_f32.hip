@@ -372,9 +372,9 @@ int gemm_pick_shape(int M, int N)
     return best;
 }
 
-int64_t gemm_plan_splits(int M, int N, int K, int* splits, int prec)
+int64_t gemm_plan_splits(int M, int N, int K, int* splits, int prec, int in16)
 {
-    if (prec) return gemm_h16_plan_splits(M, N, K, splits, prec);
+    if (prec) return gemm_h16_plan_splits(M, N, K, splits, prec, in16);
     const ShapeInfo& sh = kShapes[gemm_pick_shape(M, N)];
     const int mt = (M + sh.bm - 1) / sh.bm, nt = (N + sh.bn - 1) / sh.bn;
     const int ktiles = (K + BK - 1) / BK;
@@ -519,7 +519,7 @@ static int gemm_entry(const float* A_dev, int64_t lda, int32_t a_kcontig, const 
     g.in16 = (prec & 0x100) ? 1 : 0;
     prec &= 0xff;
     int splits = 1;
-    const int64_t need = gemm_plan_splits(M, N, K, &splits, prec);
+    const int64_t need = gemm_plan_splits(M, N, K, &splits, prec, g.in16 && a_kcontig == b_kcontig);
     if (splits > 1 && workspace_dev && workspace_bytes >= (size_t)need * sizeof(float)) {
         g.splits = splits;
         g.splitk_ws = (float*)workspace_dev;

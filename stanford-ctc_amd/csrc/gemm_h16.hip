@@ -381,20 +381,24 @@ __global__ __launch_bounds__(HTile<BIG>::NT, BIG ? 2 : X_OCC) void gemm_x16_kern
 
 // the 256x256 tile when the output is large enough to give every CU whole tiles of it and its
 // padding does not cost more than it saves (H = 1824 = 7.1 x 256 pads 12 %)
-static int h16_pick_big(int M, int N)
+static int h16_pick_big(int M, int N, int K, bool g16)
 {
     const char* force = getenv("SCTC_H16_TILE");     // diagnostics: 0 / 1
     if (force) return atoi(force) ? 1 : 0;
     auto padded = [](int v, int t) { return (double)((v + t - 1) / t * t) / v; };
     const double small = padded(M, 128) * padded(N, 128), big = padded(M, 256) * padded(N, 256);
     const int64_t tiles_big = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+    // the LDS-DMA kernel runs the long-K weight gradients at twice the rate of the 128 x 128 register-staged
+    // one (cfg-5 input layer, 2048 x 640 x 64000: 0.63 ms there): it may waste up to 25 % on padding
+    // and fills the machine through split-K
+    if (g16 && K >= 4096 && tiles_big >= 8 && big <= 1.25 * small) return 1;
     return (tiles_big >= 32 && big <= 1.06 * small) ? 1 : 0;
 }
 
-int64_t gemm_h16_plan_splits(int M, int N, int K, int* splits, int prec)
+int64_t gemm_h16_plan_splits(int M, int N, int K, int* splits, int prec, int in16)
 {
     if (prec == 3) return gemm_s3_plan_splits(M, N, K, splits);
-    const int big = h16_pick_big(M, N);
+    const int big = h16_pick_big(M, N, K, in16 && gemm_g16_enabled());
     const int bm = big ? 256 : 128, occ = big ? 1 : 2;
     const int mt = (M + bm - 1) / bm, nt = (N + bm - 1) / bm;
     const int ktiles = (K + 63) / 64;
@@ -461,7 +465,7 @@ static int launch_h16(const GemmArgs& a, hipStream_t stream)
 int launch_gemm_h16_tiles(const GemmArgs& a, hipStream_t stream)
 {
     if (a.prec == 3) return launch_gemm_s3(a, stream);
-    if (h16_pick_big(a.M, a.N)) return gemm_g16_applies(a) ? launch_gemm_g16(a, stream) : launch_h16<1>(a, stream);
+    if (h16_pick_big(a.M, a.N, a.K, gemm_g16_applies(a))) return gemm_g16_applies(a) ? launch_gemm_g16(a, stream) : launch_h16<1>(a, stream);
     return launch_h16<0>(a, stream);
 }
 
