@@ -538,11 +538,11 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
             pt.begin(SCTC_PHASE_OTHER);
             // hActs[i] = hActsFor + hActsBack, brnnet.py:153
             if (h16) {
-                SCTC_TRY(launch_add16(h->act[i], h->hF, h->hB, h->act16f[i], h->act16b[i], N * LD(h->Hp), s));
-                if (h->cfg.train) {   // B operands of the recurrent weight gradient
-                    SCTC_TRY(launch_cvt16(h->hF, nullptr, h->hF16b, N * LD(h->Hp), s));
-                    SCTC_TRY(launch_cvt16(h->hB, nullptr, h->hB16b, N * LD(h->Hp), s));
-                }
+                // one pass: the 16-bit shadows of the sum (nobody reads its fp32 copy in this configuration)
+                // and, when training, the bfloat16 copies of hF / hB (B operands of the recurrent weight gradient)
+                SCTC_TRY(launch_add16(nullptr, h->hF, h->hB, h->act16f[i], h->cfg.train ? h->act16b[i] : nullptr,
+                                      N * LD(h->Hp), s, h->cfg.train ? h->hF16b : nullptr,
+                                      h->cfg.train ? h->hB16b : nullptr));
             } else {
                 SCTC_TRY(launch_add(h->act[i], h->hF, h->hB, N * LD(h->Hp), s));
             }
@@ -788,10 +788,11 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             for (int l = h->NL; l >= h->TL; --l)     // the held-back events of the layers above (see there)
                 SCTC_HIP_TRY(hipEventRecord(h->grad_ev[weight_index(h, l)], s));
             pt.begin(SCTC_PHASE_BWD_GEMM);
-            if (h16) {   // A operands of the recurrent weight gradient
-                SCTC_TRY(launch_cvt16(h->dF, nullptr, h->dF16b, N * LD(h->Hp), s));
-                SCTC_TRY(launch_cvt16(h->dBk, nullptr, h->dBk16b, N * LD(h->Hp), s));
-            }
+            // deltasOut = deltasFor + deltasBack, brnnet.py:233 -- in the fp16 configuration first, in the
+            // pass that also writes the bfloat16 copies of dF / dBk (A operands of the recurrent weight
+            // gradient); its fp32 sum has no reader (the delta GEMM below takes the bfloat16 shadow)
+            if (h16) SCTC_TRY(launch_add16(nullptr, h->dF, h->dBk, nullptr, bufs16[which], N * LD(h->Hp), s,
+                                           h->dF16b, h->dBk16b));
             // dwtf = deltasFor[:,1:T] . hActsFor[:,0:T-1]^T ; dwtb = deltasBack[:,0:T-1] . hActsBack[:,1:T]^T
             // (brnnet.py:227-230) over the (lo = frame t, hi = frame t+1) row pairs of every utterance
             for (int k = 0; k < 2; ++k) {
@@ -841,8 +842,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             }
             // deltasOut = deltasFor + deltasBack, brnnet.py:233
             pt.begin(SCTC_PHASE_OTHER);
-            if (h16) SCTC_TRY(launch_add16(d_out, h->dF, h->dBk, nullptr, bufs16[which], N * LD(h->Hp), s));
-            else SCTC_TRY(launch_add(d_out, h->dF, h->dBk, N * LD(h->Hp), s));
+            if (!h16) SCTC_TRY(launch_add(d_out, h->dF, h->dBk, N * LD(h->Hp), s));
         }
         d_in = d_out;
         d_in16 = bufs16[which];
@@ -1122,9 +1122,9 @@ int sctc_brnn_debug_buffer(sctc_brnn_t h, int32_t which, void** dev_ptr, int64_t
                            int64_t* ld)
 {
     SCTC_CHECK_ARG(h && dev_ptr && rows && cols && ld, "debug_buffer: null argument");
-    SCTC_CHECK_ARG(!(h->cfg.operand_dtype == SCTC_F16 && ((which >= 1 && which <= h->NL && which != h->TL) || which == 200)),
-                   "debug_buffer: in the fp16-operand configuration the ReLU layers' activations and the deltas "
-                   "between them exist as 16-bit shadows only (buffer %d has no fp32 copy)", which);
+    SCTC_CHECK_ARG(!(h->cfg.operand_dtype == SCTC_F16 && ((which >= 1 && which <= h->NL) || which == 200)),
+                   "debug_buffer: in the fp16-operand configuration the hidden layers' activations and the deltas "
+                   "between them exist as 16-bit shadows only (buffer %d has no fp32 copy; 0, 100, 101 do)", which);
     const float* p = nullptr;
     int64_t c = h->Hp, l = LD(h->Hp);
     if (which >= 0 && which <= h->NL) {

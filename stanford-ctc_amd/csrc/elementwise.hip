@@ -63,17 +63,22 @@ __global__ __launch_bounds__(256) void cvt16_kernel(const float4* __restrict__ s
     }
 }
 
-// out = a + b (fp32) plus its 16-bit shadows
+// out = a + b (fp32; nullable: the fp16 configuration reads the sum through its shadows only) plus its
+// 16-bit shadows, plus (a16b / b16b, nullable) the bfloat16 copies of the two inputs themselves -- the
+// operands of the recurrent weight gradient, which used to be two more passes over the same matrices
 __global__ __launch_bounds__(256) void add16_kernel(float4* __restrict__ out, const float4* __restrict__ a,
                                                     const float4* __restrict__ b, ushort4* __restrict__ o16a,
-                                                    ushort4* __restrict__ o16b, int64_t n4)
+                                                    ushort4* __restrict__ o16b, ushort4* __restrict__ a16b,
+                                                    ushort4* __restrict__ b16b, int64_t n4)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 x = a[i], y = b[i];
         const float4 v = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
-        out[i] = v;
+        if (out) out[i] = v;
         if (o16a) o16a[i] = make_ushort4(to_f16(v.x), to_f16(v.y), to_f16(v.z), to_f16(v.w));
         if (o16b) o16b[i] = make_ushort4(to_bf16(v.x), to_bf16(v.y), to_bf16(v.z), to_bf16(v.w));
+        if (a16b) a16b[i] = make_ushort4(to_bf16(x.x), to_bf16(x.y), to_bf16(x.z), to_bf16(x.w));
+        if (b16b) b16b[i] = make_ushort4(to_bf16(y.x), to_bf16(y.y), to_bf16(y.z), to_bf16(y.w));
     }
 }
 
@@ -297,12 +302,12 @@ int launch_cvt16(const float* src, uint16_t* dst_f16, uint16_t* dst_bf16, int64_
 }
 
 int launch_add16(float* out, const float* a, const float* b, uint16_t* o_f16, uint16_t* o_bf16, int64_t n,
-                 hipStream_t s)
+                 hipStream_t s, uint16_t* a_bf16, uint16_t* b_bf16)
 {
     if (n <= 0) return SCTC_OK;
     SCTC_CHECK_ARG(n % 4 == 0, "add: element count must be a multiple of 4");
     hipLaunchKernelGGL(add16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, (float4*)out, (const float4*)a,
-                       (const float4*)b, (ushort4*)o_f16, (ushort4*)o_bf16, n / 4);
+                       (const float4*)b, (ushort4*)o_f16, (ushort4*)o_bf16, (ushort4*)a_bf16, (ushort4*)b_bf16, n / 4);
     SCTC_HIP_TRY(hipGetLastError());
     return SCTC_OK;
 }
