@@ -390,7 +390,7 @@ def main():
                          "measured": "live, inside the %d timed steps: one hipEvent per kernel group on the "
                                      "compute stream (sctc_brnn_set_profiling(h, 2): recorded asynchronously, "
                                      "resolved after each step, no sync added); phase_ms_exact_timers is one "
-                                     "extra step with synchronising timers; profiles/r03_bench_kernel_stats.csv "
+                                     "extra step with synchronising timers; profiles/r04_bench_kernel_stats.csv "
                                      "is rocprofv3's view of the same command" % args.steps,
                          "launches_per_step": n_gemm_launches,
                          "avg_launch_ms": gemm_ms / n_gemm_launches,
@@ -461,6 +461,12 @@ def main():
                 out["roofline_ctc"]["traffic"] = sum(
                     c[k]["fetch_bytes"] + c[k]["write_bytes"]
                     for k in ("softmax_rows_kernel", "ctc_lattice_kernel", "ctc_grad_kernel"))
+                out["roofline_ctc"]["traffic_note"] = (
+                    "rocprofv3 FETCH_SIZE + WRITE_SIZE of the three kernels, RAW: the guide's x2 correction of "
+                    "FETCH_SIZE is calibrated for 16 B/lane reads only, these kernels read 4-8 B per lane "
+                    "(with x2 on the fetches: %.3g bytes)" % sum(
+                        c[k]["fetch_bytes_x2"] + c[k]["write_bytes"]
+                        for k in ("softmax_rows_kernel", "ctc_lattice_kernel", "ctc_grad_kernel")))
         if dp is None and not args.no_side:
             side_measurements(out, net, feats, labels, Ts, rs, torch, B, T, D)
             recurrent_by_minibatch(out, torch, cfg)

@@ -68,6 +68,27 @@ struct GemmArgs {
 // the 16-bit value v (float16 or bfloat16 bits) is > 0
 __host__ __device__ inline bool gemm_pos16(unsigned v) { return (v & 0x8000u) == 0u && (v & 0x7fffu) != 0u; }
 
+// XCD-aware, bijective block -> tile remap, correct for split-K grids (round 4).  Workgroups are dealt to
+// the 8 XCDs round-robin by their LINEAR id (blockIdx.y * gridDim.x + blockIdx.x for a 2-D grid), and an
+// XCD should walk CONSECUTIVE tiles of ONE K slice, so that the blocks it runs at a time share operand
+// panels in its 4 MiB L2.  Rounds 1-3 took blockIdx.x % 8 for the XCD: right for gridDim.y == 1, but with
+// split-K (the weight gradients: 285 tiles x 7 K slices at cfg-3) slice y starts at XCD (y * 285) % 8, the
+// "XCD c" group of tiles was in fact spread over all eight L2s, and the launch fetched 3.5 GB from the
+// memory side where the forward GEMM of the same size fetches 2.0 GB (PMC, profiles/r04_*).
+// Within slice y: block x runs on XCD (x + sh) % 8, sh = (y * nblk) % 8; the tiles are handed out class by
+// class (XCD 0's blocks first), position inside a class in dispatch order.
+#ifdef __HIPCC__
+__device__ __forceinline__ int gemm_xcd_tile(int nblk)
+{
+    const int sh = (int)(((long long)blockIdx.y * nblk) & 7);
+    const int lin = (int)blockIdx.x + sh, c = lin & 7;
+    auto count = [](int a, int cls) { return (a + 7 - cls) >> 3; };     // integers in [0, a) congruent to cls mod 8
+    int before = 0;
+    for (int k = 0; k < c; ++k) before += count(nblk + sh, k) - count(sh, k);
+    return before + count(lin, c) - count(sh, c);
+}
+#endif
+
 // picks the split-K factor; returns the workspace floats needed (0 when splits == 1)
 int64_t gemm_plan_splits(int M, int N, int K, int* splits, int prec = 0, int in16 = 0);   // in16: operands 16-bit in memory, same layout
 int launch_gemm_f32(GemmArgs a, hipStream_t stream);     // dispatches on a.prec

@@ -90,12 +90,7 @@ __global__ __launch_bounds__(TileCfg<SHAPE>::NT, TileCfg<SHAPE>::OCC) void gemm_
     const int M = p.M, N = p.N, K = p.K;
     const int mt = (M + BM - 1) / BM, nt = (N + BN_ - 1) / BN_;
     const int nblk = mt * nt;
-    // XCD-aware, bijective remap (block b runs on XCD b % 8)
-    int swz;
-    {
-        const int bid = blockIdx.x, q = nblk / 8, r = nblk % 8, xcd = bid % 8;
-        swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-    }
+    const int swz = gemm_xcd_tile(nblk);      // XCD-aware, bijective, split-K aware (gemm_f32.h)
     const int tile_n = swz % nt, tile_m = swz / nt;
     const int m0 = tile_m * BM, n0 = tile_n * BN_;
 

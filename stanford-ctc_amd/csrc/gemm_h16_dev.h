@@ -74,11 +74,7 @@ template <> struct H16<true> {
 };
 
 // XCD-aware, bijective block remap (block b runs on XCD b % 8): an XCD walks consecutive tiles
-__device__ __forceinline__ int h16_swizzle(int nblk)
-{
-    const int bid = blockIdx.x, q = nblk / 8, r = nblk % 8, xcd = bid % 8;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-}
+__device__ __forceinline__ int h16_swizzle(int nblk) { return gemm_xcd_tile(nblk); }
 
 // One k-tile of MFMAs from the LDS image (LDH = row stride in halves, KB = k per tile)
 template <bool BF, int TM, int TN, int KB, int LDH>

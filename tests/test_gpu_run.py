@@ -156,6 +156,36 @@ def test_bench_two_ranks(backend):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["frames_per_step"] == 2 * 6 * 1000
     assert out["cost_check"]["rel_err"] < 1e-4
+    # the ranks exchanged their PCI bus ids: the rank -> device map is in the line; two gloo ranks on the
+    # one GPU of the box report the same id and take the device lease, RCCL ranks must sit on two devices
+    ranks = out["config"]["rccl_ranks"]
+    assert len(ranks) == 2 and out["config"]["backend"] == backend
+    same = ranks[0].split(":", 1)[1] == ranks[1].split(":", 1)[1]
+    assert out["config"]["shared_device_mode"] == same
+    assert same == (backend == "gloo")
+
+
+def test_bench_four_ranks_gloo_on_one_gpu():
+    """the driver's N = 4 launch line rehearsed on the one GPU of the box (gloo, all four ranks under the
+    device lease): rank -> bus-id exchange over four ranks, four shards, MAX-over-ranks timing, one line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCTC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+           "--master-addr", "127.0.0.1", "--master-port", "29543",
+           os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--batch", "3",
+           "--no-side", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 4 and out["value"] > 0 and out["config"]["frames_per_step"] == 4 * 3 * 1000
+    assert out["cost_check"]["rel_err"] < 1e-4
+    ranks = out["config"]["rccl_ranks"]
+    assert len(ranks) == 4 and len({r.split(":", 1)[1] for r in ranks}) == 1      # one physical GPU
+    assert out["config"]["shared_device_mode"] is True
+    assert res.stderr.count("shared=1") == 4                                        # one line per rank
 
 
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
