@@ -720,7 +720,7 @@ def cfg5_fp16(out, torch):
         gemm_ms = ph["fwd_gemm"] + ph["bwd_gemm"]
         res["minibatch_%d" % B] = {
             "value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "phase_ms": ph,
-            "roofline_gemm": {"bound": "mfma", "kernel": "gemm_x16_kernel (f16 fwd / bf16 bwd shadow operands, f32 accumulate)",
+            "roofline_gemm": {"bound": "mfma", "kernel": "gemm_g16_kernel (LDS-DMA; gemm_x16_kernel for the gathered / small shapes): f16 fwd / bf16 bwd shadow operands, f32 accumulate",
                               "achieved": gm.value / (gemm_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": gm.value / (gemm_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
                               "note": "16-bit shadow copies of activations / deltas / weights are written by "

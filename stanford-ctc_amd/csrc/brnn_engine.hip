@@ -110,6 +110,7 @@ struct sctc_brnn {
     bool ev_ready = false;
     float phase_ms[SCTC_N_PHASES];
     int rec_sync_mode = 0;
+    bool fuse_add = true;      // env SCTC_FUSE_ADD=0: the two sums around the temporal layer by add_kernel (A/B, bit-identity tests)
     int rec_poll_delay = -1;   // env SCTC_REC_POLL_DELAY (s_sleep units before a step's first poll; default by layer size)
     int rec_variant = 0;   // env SCTC_REC_VARIANT: 1 forces the one-workgroup-per-CU recurrent kernel, 3 the per-step fallback
     int rec_force_fallback = 0;   // set while a timed-out step is retried on the per-step fallback
@@ -465,6 +466,7 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
     } else {
         SCTC_TRY(launch_gather_rows(h->X0, LD(h->Dp), mb->feats_dev, h->D, h->d_src_row, N, h->D, s));
     }
+    bool fused_sum = false;   // the sum of the two recurrent outputs is left to the next GEMM (native fp32 only)
     for (int i = 1; i <= h->NL + 1; ++i) {
         pt.begin(SCTC_PHASE_FWD_GEMM);
         const int l = i - 1;
@@ -487,6 +489,14 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
         g.ldc = LD(outp);
         g.relu = (i <= h->NL && i != h->TL) ? 1 : 0;             // brnnet.py:155-157
         g.prec = fwd_prec(h->cfg.operand_dtype);                 // SCTC_F16 -> forward: float16 operands
+        if (fused_sum) {
+            // hActs[TL] = hActsFor + hActsBack (brnnet.py:153) is formed while this GEMM stages its A operand;
+            // the blocks of the first N tile store it to act[TL] for the weight gradient of this layer
+            g.A = h->hF;
+            g.A2 = h->hB;
+            g.a_sum = h->act[i - 1];
+            fused_sum = false;
+        }
         if (h16) {
             g.in16 = 1;
             g.A = reinterpret_cast<const float*>(h->act16f[i - 1]);
@@ -543,6 +553,8 @@ static int run_forward(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s, Ph
                 SCTC_TRY(launch_add16(nullptr, h->hF, h->hB, h->act16f[i], h->cfg.train ? h->act16b[i] : nullptr,
                                       N * LD(h->Hp), s, h->cfg.train ? h->hF16b : nullptr,
                                       h->cfg.train ? h->hB16b : nullptr));
+            } else if (g.prec == 0 && h->fuse_add) {
+                fused_sum = true;
             } else {
                 SCTC_TRY(launch_add(h->act[i], h->hF, h->hB, N * LD(h->Hp), s));
             }
@@ -668,6 +680,7 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
         }
     }
     int which = 0;
+    bool fused_sum = false;   // the sum of the two BPTT outputs is left to the next weight gradient (native fp32 only)
     for (int i = h->NL; i >= 0; --i) {          // brnnet.py:191-243
         pt.begin(SCTC_PHASE_BWD_GEMM);
         const sctc_tensor_info& wi = h->tinfo[weight_index(h, i)];
@@ -680,6 +693,15 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             g.A = d_in;             // A(m=out, k=frame) = d_in[frame][out]
             g.lda = d_in_ld;
             g.a_kcontig = 0;
+            if (fused_sum) {
+                // deltasOut = deltasFor + deltasBack (brnnet.py:233) is formed while this GEMM stages its A
+                // operand (its column sums, the bias gradient, are taken of the sum); the blocks of the first
+                // N tile store it to d_in for the delta GEMM below
+                g.A = h->dF;
+                g.A2 = h->dBk;
+                g.a_sum = const_cast<float*>(d_in);
+                fused_sum = false;
+            }
             g.B = h->act[i];        // B(k=frame, n=in) = act[frame][in]
             g.ldb = LD(inp);
             g.b_kcontig = 0;
@@ -842,7 +864,10 @@ static int run_backward(sctc_brnn* h, int flags, hipStream_t s, PhaseTimer& pt)
             }
             // deltasOut = deltasFor + deltasBack, brnnet.py:233
             pt.begin(SCTC_PHASE_OTHER);
-            if (!h16) SCTC_TRY(launch_add(d_out, h->dF, h->dBk, N * LD(h->Hp), s));
+            if (!h16) {
+                if (bprec == 0 && h->fuse_add) fused_sum = true;
+                else SCTC_TRY(launch_add(d_out, h->dF, h->dBk, N * LD(h->Hp), s));
+            }
         }
         d_in = d_out;
         d_in16 = bufs16[which];
@@ -944,6 +969,7 @@ int sctc_brnn_create(const sctc_brnn_config* cfg, float* params_dev, float* grad
     h->rec_variant = rv ? atoi(rv) : 0;
     const char* pd = getenv("SCTC_REC_POLL_DELAY");
     h->rec_poll_delay = pd ? atoi(pd) : -1;
+    if (const char* fa = getenv("SCTC_FUSE_ADD")) h->fuse_add = atoi(fa) != 0;
     const char* dbg = getenv("SCTC_REC_DEBUG");
     h->rec_debug_on = dbg ? atoi(dbg) : 0;
     *out = h;

@@ -64,6 +64,14 @@ struct GemmArgs {
     int32_t skip_c32;
     const uint16_t* mask16;
     int64_t ldmask16;
+    // prec 0 only: A is the SUM of two matrices of the same layout and leading dimension, A(m,k) =
+    // A[..] + A2[..], added while the tile is staged (brnnet.py:153 hActs = hActsFor + hActsBack is the A
+    // operand of the next layer's forward GEMM, :233 deltasOut = deltasFor + deltasBack the A operand of
+    // the next weight gradient; the fp32 sum is the one add_kernel computed: bit-identical).  `a_sum`
+    // (nullable, same layout as A): the blocks of the first N tile also store the sum there, once per
+    // element, for the sum's later readers.  Layouts NT and TN only, no row gather.
+    const float* A2;
+    float* a_sum;
 };
 // the 16-bit value v (float16 or bfloat16 bits) is > 0
 __host__ __device__ inline bool gemm_pos16(unsigned v) { return (v & 0x8000u) == 0u && (v & 0x7fffu) != 0u; }

@@ -70,7 +70,7 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& p, float v, int r
     return v;
 }
 
-template <bool AK, bool BKC, int SHAPE>
+template <bool AK, bool BKC, int SHAPE, bool S2 = false>
 __global__ __launch_bounds__(TileCfg<SHAPE>::NT, TileCfg<SHAPE>::OCC) void gemm_f32_kernel(GemmArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -126,6 +126,9 @@ __global__ __launch_bounds__(TileCfg<SHAPE>::NT, TileCfg<SHAPE>::OCC) void gemm_
         // Item f of a tile: K-contiguous -> row f / KQ, k = 4 (f % KQ);
         //                   row-contiguous -> k-row f / (rows/4), column 4 (f % (rows/4)).
         float4 ra[NLDA], rb[NLDB];
+        float4 ra2[S2 ? NLDA : 1];                 // S2: the second addend of A (GemmArgs::A2)
+        const int64_t d2 = S2 ? p.A2 - p.A : 0;    // same layout: one uniform element offset
+        const bool sum_out = S2 && p.a_sum != nullptr && tile_n == 0;
         const float* pa[NLDA];
         const float* pb[NLDB];
         int ia[NLDA], ib[NLDB];   // row-contiguous operands: (gathered) row of the next tile
@@ -159,8 +162,10 @@ __global__ __launch_bounds__(TileCfg<SHAPE>::NT, TileCfg<SHAPE>::OCC) void gemm_
                 const int f = min(tid + NTHREADS * q, NA - 1);
                 if constexpr (AK) {
                     ra[q] = *reinterpret_cast<const float4*>(pa[q] + min(k0 + 4 * (f % KQ), Kc4));
+                    if constexpr (S2) ra2[q] = *reinterpret_cast<const float4*>(pa[q] + d2 + min(k0 + 4 * (f % KQ), Kc4));
                 } else {
                     ra[q] = *reinterpret_cast<const float4*>(pa[q] + (uint32_t)ia[q] * (uint32_t)p.lda);
+                    if constexpr (S2) ra2[q] = *reinterpret_cast<const float4*>(pa[q] + d2 + (uint32_t)ia[q] * (uint32_t)p.lda);
                     const int kn = min(k0 + BK + f / MQ, Kc1);
                     ia[q] = p.idx_a ? p.idx_a[kn] : kn;
                 }
@@ -190,6 +195,15 @@ __global__ __launch_bounds__(TileCfg<SHAPE>::NT, TileCfg<SHAPE>::OCC) void gemm_
             for (int q = 0; q < NLDA; ++q) {
                 const int f = tid + NTHREADS * q;
                 if (NA % NTHREADS != 0 && f >= NA) continue;
+                if constexpr (S2) {   // the sum, and its one stored copy (in-range elements only: clamped loads repeat)
+                    ra[q].x += ra2[q].x; ra[q].y += ra2[q].y; ra[q].z += ra2[q].z; ra[q].w += ra2[q].w;
+                    if (sum_out) {
+                        const int row = AK ? m0 + f / KQ : kt * BK + f / MQ;
+                        const int col = AK ? kt * BK + 4 * (f % KQ) : m0 + 4 * (f % MQ);
+                        if (row < (AK ? M : K) && col < (AK ? K : M))
+                            *reinterpret_cast<float4*>(p.a_sum + (int64_t)row * p.lda + col) = ra[q];
+                    }
+                }
                 if constexpr (AK) {
                     const int r = f / KQ, kq = 4 * (f % KQ);
                     if (tail) zero_tail(ra[q], kt * BK + kq);
@@ -401,12 +415,13 @@ static int launch_tiles(GemmArgs a, hipStream_t stream)
     dim3 grid(mt * nt, a.splits), block(TileCfg<SHAPE>::NT);
     const size_t smem = sizeof(float) * lds_floats(BM, BN_);  // 2 operands x 2 buffers
     void (*kern)(GemmArgs) = nullptr;
-    if (a.a_kcontig && a.b_kcontig) kern = gemm_f32_kernel<true, true, SHAPE>;
+    if (a.A2) kern = a.a_kcontig ? gemm_f32_kernel<true, true, SHAPE, true> : gemm_f32_kernel<false, false, SHAPE, true>;
+    else if (a.a_kcontig && a.b_kcontig) kern = gemm_f32_kernel<true, true, SHAPE>;
     else if (a.a_kcontig && !a.b_kcontig) kern = gemm_f32_kernel<true, false, SHAPE>;
     else if (!a.a_kcontig && a.b_kcontig) kern = gemm_f32_kernel<false, true, SHAPE>;
     else kern = gemm_f32_kernel<false, false, SHAPE>;
-    static bool attr_set[4] = {false, false, false, false};
-    const int vi = (a.a_kcontig ? 2 : 0) + (a.b_kcontig ? 1 : 0);
+    static bool attr_set[6] = {false, false, false, false, false, false};
+    const int vi = a.A2 ? 4 + (a.a_kcontig ? 1 : 0) : (a.a_kcontig ? 2 : 0) + (a.b_kcontig ? 1 : 0);
     if (!attr_set[vi]) {
         SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -439,6 +454,10 @@ int launch_gemm_f32(GemmArgs a, hipStream_t stream)
     else SCTC_CHECK_ARG(a.M % 4 == 0, "gemm: M must be a multiple of 4 (A row-contig)");
     if (a.b_kcontig) SCTC_CHECK_ARG(a.K % 4 == 0, "gemm: K must be a multiple of 4 (B K-contig)");
     else SCTC_CHECK_ARG(a.N % 4 == 0, "gemm: N must be a multiple of 4 (B row-contig)");
+    SCTC_CHECK_ARG(!a.A2 || (a.prec == 0 && a.a_kcontig == a.b_kcontig && !a.idx_a && ((uintptr_t)a.A2 & 15) == 0 &&
+                              ((uintptr_t)a.a_sum & 15) == 0),
+                   "gemm: a two-addend A operand needs prec 0, layout NT or TN, no row gather, 16-byte alignment");
+    SCTC_CHECK_ARG(!a.a_sum || a.A2, "gemm: a_sum without A2");
     if (a.splits < 1) a.splits = 1;
     if (a.splits > 1) SCTC_CHECK_ARG(a.splitk_ws != nullptr, "gemm: split-K without workspace");
     if (a.prec) {

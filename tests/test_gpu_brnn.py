@@ -317,6 +317,41 @@ def _all_grads(net, NL):
     return [net.grad[i][0].copy_to_host().astype(np.float64).copy() for i in range(NL + 3)]
 
 
+@pytest.mark.parametrize("H,NL,TL,B", [(96, 3, 2, 5), (200, 4, 1, 3), (64, 4, 3, 8), (1824, 3, 2, 2), (132, 2, 1, 1)])
+def test_sums_around_the_temporal_layer_fused_into_gemms(mods, monkeypatch, gemm_mode, H, NL, TL, B):
+    """brnnet.py:153 (hActs = hActsFor + hActsBack) and :233 (deltasOut = deltasFor + deltasBack) are formed
+    by the GEMMs that consume them (GemmArgs::A2: two addends summed while the A tile is staged; the sum is
+    stored once for its later readers): every cost and gradient is BIT-identical to the step that runs
+    add_kernel (SCTC_FUSE_ADD=0) -- temporal layer first, in the middle and last admissible (NL - 1), layer sizes that are and
+    are not multiples of the tile shapes, ragged minibatches"""
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(100 + H)
+    D, A = 24, 33
+    Ts = [int(t) for t in rs.randint(2, 38, size=B)]
+    Ts[0] = 37
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 7)).astype(np.int32) for T in Ts]
+    out = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("SCTC_FUSE_ADD", fuse)
+        net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B, reg=1e-3)
+        costs, _, skips = net.costAndGradBatch(datas, labs)
+        out.append((costs.copy(), skips.copy(), _all_grads(net, NL),
+                    [net.grad[i][1].copy_to_host().copy() for i in range(NL + 1)]))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    for a, b in zip(out[0][2] + out[0][3], out[1][2] + out[1][3]):
+        np.testing.assert_array_equal(a, b)
+    if gemm_mode == "f32" and H < 1000:      # and the fused step is the oracle's step
+        with np.errstate(all="ignore"):
+            _, g_ref, _, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+        monkeypatch.setenv("SCTC_FUSE_ADD", "1")
+        net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
+        net.costAndGradBatch(datas, labs)
+        check_grads(net, g_ref, NL)
+
+
 def test_recurrent_two_chain_kernel_vs_oracle(mods, monkeypatch):
     """17..32 utterances run the two-chains-per-CU recurrent kernel (recurrent.hip): ragged
     minibatch of 24 at H=512 against the float64 oracle, and against the one-workgroup-per-CU
