@@ -255,7 +255,7 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
     size_t ctc_bytes = 0;
     void* ctc_ws = nullptr;
     if (c->train) {
-        ctc_bytes = align256(sizeof(CtcUtt) * Bm) + align256(sizeof(int32_t) * F) +
+        ctc_bytes = align256(sizeof(CtcUtt) * Bm) + align256(sizeof(int32_t) * (2 * F + (int64_t)Bm * (d.A + 1))) +
                     align256(sizeof(double) * 2 * Bm) + align256(sizeof(int32_t) * 2 * Bm) +
                     2 * align256(sizeof(double) * F * CTC_LP_MAX);
         ctc_ws = ar.take<char>(ctc_bytes);

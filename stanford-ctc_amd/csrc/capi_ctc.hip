@@ -56,7 +56,8 @@ int ctc_make_plan(int B, int A, int blank, const int32_t* T_b, const int32_t* U_
     plan->max_T = max_T;
     plan->lat_elems = frames * plan->lp;
     plan->n_labels = n_labels;
-    plan->bytes = align256(sizeof(CtcUtt) * B) + align256(sizeof(int32_t) * n_labels) +
+    // labels, the same labels grouped by value (ctc_grad's per-label sums), group offsets
+    plan->bytes = align256(sizeof(CtcUtt) * B) + align256(sizeof(int32_t) * (2 * n_labels + (int64_t)B * (A + 1))) +
                   align256(sizeof(double) * 2 * B) + align256(sizeof(int32_t) * 2 * B) +
                   2 * align256(sizeof(double) * plan->lat_elems);
     return SCTC_OK;
@@ -66,7 +67,8 @@ int ctc_make_plan(int B, int A, int blank, const int32_t* T_b, const int32_t* U_
 // it the function synchronises the stream before its local staging goes away.
 struct CtcHostStage {
     std::vector<CtcUtt> utts;
-    std::vector<int32_t> labels;
+    std::vector<int32_t> labels;    // [n_labels] labels | [n_labels] odd states grouped by label | [B][A+1] group offsets
+    std::vector<int32_t> cursor;
 };
 
 template <typename R>
@@ -77,7 +79,8 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
     Arena ar;
     ar.init(ws, ws_bytes);
     CtcUtt* d_utts = ar.take<CtcUtt>(plan.B);
-    int32_t* d_labels = ar.take<int32_t>(plan.n_labels);
+    const int64_t n_int = 2 * plan.n_labels + (int64_t)plan.B * (plan.A + 1);
+    int32_t* d_labels = ar.take<int32_t>(n_int);
     double* d_ll = ar.take<double>(2 * plan.B);
     int32_t* d_skip2 = ar.take<int32_t>(2 * plan.B);
     double* d_alpha = ar.take<double>(plan.lat_elems);
@@ -89,7 +92,7 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
     CtcHostStage local;
     CtcHostStage& st = keep ? *keep : local;
     st.utts.resize(plan.B);
-    st.labels.resize(plan.n_labels);
+    st.labels.resize(n_int);
     std::vector<CtcUtt>& utts = st.utts;
     std::vector<int32_t>& labels = st.labels;
     int64_t lat_off = 0, lab_off = 0;
@@ -106,12 +109,21 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
                            "outside the alphabet [0,%d)", i, b, src[i], plan.A);
             labels[lab_off + i] = src[i];
         }
+        // stable counting sort of the label positions by label value: the gradient kernel sums a label's states
+        // in ascending order (ctc_fast.pyx:120-131) without scanning the whole row for every label
+        int32_t* start = labels.data() + 2 * plan.n_labels + (int64_t)b * (plan.A + 1);
+        int32_t* grouped = labels.data() + plan.n_labels + lab_off;
+        std::fill(start, start + plan.A + 1, 0);
+        for (int i = 0; i < u.U; ++i) ++start[src[i] + 1];
+        for (int k = 0; k < plan.A; ++k) start[k + 1] += start[k];
+        st.cursor.assign(start, start + plan.A);
+        for (int i = 0; i < u.U; ++i) grouped[st.cursor[src[i]]++] = 2 * i + 1;
         lat_off += (int64_t)u.T * plan.lp;
         lab_off += u.U;
     }
     SCTC_HIP_TRY(hipMemcpyAsync(d_utts, utts.data(), sizeof(CtcUtt) * plan.B,
                                 hipMemcpyHostToDevice, stream));
-    SCTC_HIP_TRY(hipMemcpyAsync(d_labels, labels.data(), sizeof(int32_t) * plan.n_labels,
+    SCTC_HIP_TRY(hipMemcpyAsync(d_labels, labels.data(), sizeof(int32_t) * n_int,
                                 hipMemcpyHostToDevice, stream));
 
     CtcLatticeArgs<R> la;
@@ -139,6 +151,8 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
     ga.lp = plan.lp;
     ga.rowbase = bt->rowbase_dev;
     ga.labels = d_labels;
+    ga.by_label = d_labels + plan.n_labels;
+    ga.label_start = d_labels + 2 * plan.n_labels;
     ga.alpha = d_alpha;
     ga.beta = d_beta;
     ga.ll = d_ll;

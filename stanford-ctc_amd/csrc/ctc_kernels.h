@@ -40,6 +40,10 @@ struct CtcGradArgs {
     int32_t A, blank, lp;
     const int32_t* rowbase;
     const int32_t* labels;
+    // the odd (label) states of every utterance grouped by label, ascending inside a group: by_label[lab_off + j]
+    // = state index 2i+1, group k = [label_start[b*(A+1) + k], label_start[b*(A+1) + k + 1]) (host-built, capi_ctc.hip)
+    const int32_t* by_label;
+    const int32_t* label_start;
     const double* alpha;
     const double* beta;
     const double* ll;

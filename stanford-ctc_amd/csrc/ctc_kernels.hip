@@ -571,6 +571,12 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<RI> p)
     const int L4 = (L + 3) & ~3;  // vector reads below run to L4; pad label = -1 never matches
     for (int s = threadIdx.x; s < L4; s += 256)
         lab_s[s] = s >= L ? -1 : ((s & 1) ? seq[(s - 1) >> 1] : p.blank);
+    // [LP/2] odd states grouped by label, [A+1] group offsets (behind the four waves' copies of the frame's probabilities)
+    int32_t* ord_s = reinterpret_cast<int32_t*>(smem + (size_t)LP * sizeof(int32_t) + 4 * (size_t)LP * sizeof(R) +
+                                                4 * (size_t)((p.A + 3) & ~3) * sizeof(RI));
+    int32_t* start_s = ord_s + LP / 2;
+    for (int j = threadIdx.x; j < U; j += 256) ord_s[j] = p.by_label[u.lab_off + j];
+    for (int k = threadIdx.x; k <= p.A; k += 256) start_s[k] = p.label_start[(int64_t)b * (p.A + 1) + k];
     __syncthreads();
 
     const int skip = p.skip2[2 * b] | p.skip2[2 * b + 1];
@@ -623,7 +629,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<RI> p)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     R zpart = (R)0;
     constexpr int NB = 8;
-    for (int s0 = lane; s0 < L4; s0 += 64 * NB) {
+    const int L32 = (L + 31) & ~31;   // <= LP; the pads ab[L .. L32) are written as +0 (read by the sums below)
+    for (int s0 = lane; s0 < L32; s0 += 64 * NB) {
         R av[NB], bv[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -638,7 +645,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<RI> p)
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int s = s0 + 64 * i;
-            if (s < L4) {
+            if (s < L32) {
                 R v = (R)0;
                 if (s < L) {
                     if (p.lazy) v = scalbn(av[i], ea) * scalbn(bv[i], eb);
@@ -657,18 +664,46 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<RI> p)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // grad[k, t] = sum of ab over the states of label k, in ascending s like the reference (:120-131).  Every
+    // lane used to scan the whole row for its label (L compare-select-adds per lane: 44 k issue cycles per frame
+    // at L = 1601); now the blank lane adds the even states and every other lane walks its host-built list of
+    // states (by_label): the frame costs the blank lane's chain of (L+1)/2 dependent additions.  A label equal
+    // to the blank id (legal) interleaves odd states into the blank sum: that lane then scans.
     using V4 = typename Vec<R>::v4;
     const V4* ab4 = reinterpret_cast<const V4*>(ab);
-    const int4* lab4 = reinterpret_cast<const int4*>(lab_s);
     for (int k = lane; k < p.A; k += 64) {
         R g = (R)0;
-        for (int s4 = 0; s4 < L4 / 4; ++s4) {   // ascending s == the reference's order (:120-131)
-            const V4 v = ab4[s4];
-            const int4 l = lab4[s4];
-            if (l.x == k) g += v.x;
-            if (l.y == k) g += v.y;
-            if (l.z == k) g += v.z;
-            if (l.w == k) g += v.w;
+        const int j0 = start_s[k], j1 = start_s[k + 1];
+        if (k == p.blank) {
+            if (j1 == j0) {
+                // eight 4-state groups fetched ahead of their 16 dependent additions: the LDS latency (the whole
+                // cost of a one-group-per-trip loop: 21 us per frame) is paid once per 32 states; states
+                // L .. L32-1 hold +0 (phase 1)
+                for (int s4 = 0; s4 < L32 / 4; s4 += 8) {
+                    V4 v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = ab4[s4 + i];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        g += v[i].x;
+                        g += v[i].z;
+                    }
+                }
+            } else {
+                for (int s = 0; s < L; ++s)
+                    if (lab_s[s] == k) g += ab[s];
+            }
+        } else {
+            for (int j = j0; j < j1; j += 4) {      // four list entries per trip; entries past the end read the zero pad ab[L]
+                int idx[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) idx[i] = ord_s[min(j + i, j1 - 1)];
+                R a[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = ab[j + i < j1 ? idx[i] : L];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g += a[i];
+            }
         }
         const R y = (R)y_s[k];
         const R tmp = y * Z;                        // :141
@@ -760,7 +795,8 @@ template <typename R>
 int launch_ctc_grad(const CtcGradArgs<R>& a, int B, int max_T, hipStream_t stream)
 {
     dim3 grid((max_T + 3) / 4, B), block(256);
-    size_t smem = (size_t)a.lp * sizeof(int32_t) + 4 * (size_t)a.lp * sizeof(double) + 4 * (size_t)((a.A + 3) & ~3) * sizeof(R);
+    size_t smem = (size_t)a.lp * sizeof(int32_t) + 4 * (size_t)a.lp * sizeof(double) + 4 * (size_t)((a.A + 3) & ~3) * sizeof(R) +
+                  ((size_t)a.lp / 2 + a.A + 1) * sizeof(int32_t);
     if (smem > 48 * 1024)
         SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<R>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -10,6 +10,8 @@ timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 timeout 1300 bash tools/profile_bench.sh r04 > gpurun_out/profile_r04.log 2>&1
 tail -3 gpurun_out/profile_r04.log | cut -c1-200
+# the bench line's roofline.traffic comes from the committed summary of the SAME sources: use the one just measured
+cp gpurun_out/prof_r04/pmc_summary.json profiles/r04_pmc_summary.json
 timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 python - <<'PY'
 import json
