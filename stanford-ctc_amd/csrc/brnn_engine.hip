@@ -119,6 +119,7 @@ struct sctc_brnn {
     const float* last_delta1 = nullptr;   // delta entering layer 1 (A operand of the dW1 GEMM) of the last backward pass
     // host staging of the CTC descriptors (must outlive the async uploads)
     void* ctc_stage = nullptr;
+    PinnedStage plan_stage;    // make_plan's uploads
     std::vector<int32_t> ctc_U, ctc_labels;
     std::vector<int64_t> ctc_frame_off, ctc_label_off;
 };
@@ -371,24 +372,31 @@ static int make_plan(sctc_brnn* h, const sctc_minibatch* mb, bool need_labels, h
     h->pairs_contig = h->npairs > 0;
     for (int64_t k = 1; k < h->npairs && h->pairs_contig; ++k)
         h->pairs_contig = h->idx_hi[k] == h->idx_hi[0] + k && h->idx_lo[k] == h->idx_lo[0] + k;
-    SCTC_HIP_TRY(hipMemcpyAsync(h->d_rowbase, h->rowbase.data(), sizeof(int32_t) * Tmax,
-                                hipMemcpyHostToDevice, stream));
-    SCTC_HIP_TRY(hipMemcpyAsync(h->d_nact, h->nact.data(), sizeof(int32_t) * Tmax,
-                                hipMemcpyHostToDevice, stream));
-    SCTC_HIP_TRY(hipMemcpyAsync(h->d_xbase, h->xbase.data(), sizeof(int32_t) * Tmax,
-                                hipMemcpyHostToDevice, stream));
-    SCTC_HIP_TRY(hipMemcpyAsync(h->d_Ts, h->Ts.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice,
-                                stream));
-    SCTC_HIP_TRY(hipMemcpyAsync(h->d_src_row, h->src_row.data(), sizeof(int32_t) * N,
-                                hipMemcpyHostToDevice, stream));
-    SCTC_HIP_TRY(hipMemcpyAsync(h->d_perm, h->order.data(), sizeof(int32_t) * B,
-                                hipMemcpyHostToDevice, stream));
-    if (h->npairs > 0) {
-        SCTC_HIP_TRY(hipMemcpyAsync(h->d_idx_lo, h->idx_lo.data(), sizeof(int32_t) * h->npairs,
-                                    hipMemcpyHostToDevice, stream));
-        SCTC_HIP_TRY(hipMemcpyAsync(h->d_idx_hi, h->idx_hi.data(), sizeof(int32_t) * h->npairs,
-                                    hipMemcpyHostToDevice, stream));
-    }
+    // the plan goes up through pinned staging (common.h, PinnedStage): src_row / idx_lo / idx_hi are N ints each
+    const size_t I = sizeof(int32_t);
+    const size_t total = I * (3 * (size_t)Tmax + 2 * (size_t)B + (size_t)N + 2 * (size_t)h->npairs) + 8 * 64;
+    char* pin = static_cast<char*>(h->plan_stage.acquire(total));
+    size_t off = 0;
+    auto up = [&](void* dev, const void* src, size_t bytes) -> int {
+        if (bytes == 0) return SCTC_OK;
+        const void* from = src;
+        if (pin) {
+            memcpy(pin + off, src, bytes);
+            from = pin + off;
+            off += (bytes + 63) & ~(size_t)63;
+        }
+        SCTC_HIP_TRY(hipMemcpyAsync(dev, from, bytes, hipMemcpyHostToDevice, stream));
+        return SCTC_OK;
+    };
+    SCTC_TRY(up(h->d_rowbase, h->rowbase.data(), I * Tmax));
+    SCTC_TRY(up(h->d_nact, h->nact.data(), I * Tmax));
+    SCTC_TRY(up(h->d_xbase, h->xbase.data(), I * Tmax));
+    SCTC_TRY(up(h->d_Ts, h->Ts.data(), I * B));
+    SCTC_TRY(up(h->d_src_row, h->src_row.data(), I * N));
+    SCTC_TRY(up(h->d_perm, h->order.data(), I * B));
+    SCTC_TRY(up(h->d_idx_lo, h->idx_lo.data(), I * h->npairs));
+    SCTC_TRY(up(h->d_idx_hi, h->idx_hi.data(), I * h->npairs));
+    if (pin) SCTC_HIP_TRY(h->plan_stage.uploaded(stream));
     return SCTC_OK;
 }
 

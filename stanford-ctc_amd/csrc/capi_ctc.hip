@@ -69,6 +69,9 @@ struct CtcHostStage {
     std::vector<CtcUtt> utts;
     std::vector<int32_t> labels;    // [n_labels] labels | [n_labels] odd states grouped by label | [B][A+1] group offsets
     std::vector<int32_t> cursor;
+    // a kept stage (the BRNN engine's) uploads from pinned memory: the descriptors go up in the middle of a
+    // step, between the forward pass and the lattice kernel (common.h, PinnedStage)
+    PinnedStage pinned;
 };
 
 template <typename R>
@@ -121,10 +124,18 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
         lat_off += (int64_t)u.T * plan.lp;
         lab_off += u.U;
     }
-    SCTC_HIP_TRY(hipMemcpyAsync(d_utts, utts.data(), sizeof(CtcUtt) * plan.B,
-                                hipMemcpyHostToDevice, stream));
-    SCTC_HIP_TRY(hipMemcpyAsync(d_labels, labels.data(), sizeof(int32_t) * n_int,
-                                hipMemcpyHostToDevice, stream));
+    const size_t utt_bytes = sizeof(CtcUtt) * plan.B, utt_span = align256(utt_bytes), lab_bytes = sizeof(int32_t) * n_int;
+    char* pin = keep ? static_cast<char*>(keep->pinned.acquire(utt_span + lab_bytes)) : nullptr;
+    if (pin) {
+        memcpy(pin, utts.data(), utt_bytes);
+        memcpy(pin + utt_span, labels.data(), lab_bytes);
+        SCTC_HIP_TRY(hipMemcpyAsync(d_utts, pin, utt_bytes, hipMemcpyHostToDevice, stream));
+        SCTC_HIP_TRY(hipMemcpyAsync(d_labels, pin + utt_span, lab_bytes, hipMemcpyHostToDevice, stream));
+        SCTC_HIP_TRY(keep->pinned.uploaded(stream));
+    } else {
+        SCTC_HIP_TRY(hipMemcpyAsync(d_utts, utts.data(), utt_bytes, hipMemcpyHostToDevice, stream));
+        SCTC_HIP_TRY(hipMemcpyAsync(d_labels, labels.data(), lab_bytes, hipMemcpyHostToDevice, stream));
+    }
 
     CtcLatticeArgs<R> la;
     la.utts = d_utts;

@@ -36,6 +36,55 @@ int set_error(int code, const char* fmt, ...);
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// Pinned host staging for small per-call descriptor uploads.  A hipMemcpyAsync from PAGEABLE memory beyond a few
+// tens of KB makes the runtime pin and unpin the source around the copy while the stream (and the GPU behind it)
+// waits: 2 ms for 52 KB of CTC descriptors in the middle of a cfg-5 step.  One buffer, one event: `acquire` waits
+// until the previous upload from the buffer has executed (it has, long ago, in every steady state) before the
+// caller overwrites it; `uploaded` marks the new one.  acquire() returns nullptr when pinned memory cannot be
+// had: the caller then uploads from its pageable source as before.
+struct PinnedStage {
+    void* pin = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    PinnedStage() = default;
+    PinnedStage(const PinnedStage&) = delete;
+    PinnedStage& operator=(const PinnedStage&) = delete;
+    ~PinnedStage()
+    {
+        if (ev) { if (pending) (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
+        if (pin) (void)hipHostFree(pin);
+    }
+    void* acquire(size_t bytes)
+    {
+        if (pending) { (void)hipEventSynchronize(ev); pending = false; }
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            ev = nullptr;
+            return nullptr;
+        }
+        if (cap < bytes) {
+            if (pin) (void)hipHostFree(pin);
+            pin = nullptr;
+            cap = 0;
+            const size_t want = bytes + bytes / 2 + 4096;
+            if (hipHostMalloc(&pin, want, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                pin = nullptr;
+                return nullptr;
+            }
+            cap = want;
+        }
+        return pin;
+    }
+    hipError_t uploaded(hipStream_t s)
+    {
+        const hipError_t e = hipEventRecord(ev, s);
+        pending = e == hipSuccess;
+        return e;
+    }
+};
+
 // bump allocator over a caller-provided workspace
 struct Arena {
     char* base = nullptr;
