@@ -141,7 +141,6 @@ static int derive_dims(const sctc_brnn_config* c, Dims* d)
                    "brnn: bad dimensions (inputDim %d outputDim %d layerSize %d numLayers %d)",
                    c->input_dim, c->output_dim, c->layer_size, c->num_layers);
     SCTC_CHECK_ARG(c->max_frames >= 1 && c->max_utts >= 1, "brnn: bad capacity");
-    SCTC_CHECK_ARG(c->output_dim <= 256, "brnn: alphabet %d > 256", c->output_dim);
     SCTC_CHECK_ARG(c->operand_dtype == SCTC_F32 || c->operand_dtype == SCTC_F16 || c->operand_dtype == SCTC_BF16X3,
                    "brnn: operand_dtype must be SCTC_F32, SCTC_F16 or SCTC_BF16X3 (got %d)", c->operand_dtype);
     d->D = c->input_dim;
@@ -258,7 +257,8 @@ static size_t carve(const sctc_brnn_config* c, const Dims& d, sctc_brnn* h, void
     if (c->train) {
         ctc_bytes = align256(sizeof(CtcUtt) * Bm) + align256(sizeof(int32_t) * (2 * F + (int64_t)Bm * (d.A + 1))) +
                     align256(sizeof(double) * 2 * Bm) + align256(sizeof(int32_t) * 2 * Bm) +
-                    2 * align256(sizeof(double) * F * CTC_LP_MAX);
+                    2 * align256(sizeof(double) * F * CTC_LP_MAX) +
+                    align256(sizeof(double) * 4 * (size_t)Bm * CTC_LP_MAX);   // ctc_generic.hip's row scratch
         ctc_ws = ar.take<char>(ctc_bytes);
     }
     // split-K partials: worst case over the weight-gradient GEMMs

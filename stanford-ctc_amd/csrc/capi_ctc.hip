@@ -23,11 +23,11 @@ int set_error(int code, const char* fmt, ...)
     return code;
 }
 
-int ctc_make_plan(int B, int A, int blank, const int32_t* T_b, const int32_t* U_b,
+int ctc_make_plan(int B, int A, int blank, int dtype, const int32_t* T_b, const int32_t* U_b,
                   CtcPlan* plan)
 {
     SCTC_CHECK_ARG(B >= 1, "ctc: empty batch");
-    SCTC_CHECK_ARG(A >= 1 && A <= 256, "ctc: alphabet size %d not in [1,256]", A);
+    SCTC_CHECK_ARG(A >= 1, "ctc: alphabet size %d < 1", A);
     SCTC_CHECK_ARG(blank >= 0 && blank < A, "ctc: blank id %d outside the alphabet", blank);
     int max_L = 0, max_T = 0;
     int64_t n_labels = 0, frames = 0;
@@ -41,8 +41,14 @@ int ctc_make_plan(int B, int A, int blank, const int32_t* T_b, const int32_t* U_
         frames += T_b[b];
     }
     int W = 1;
-    const int K = ctc_lattice_shape(max_L, &W);
-    SCTC_CHECK_ARG(K > 0, "ctc: label sequence too long (2U+1 = %d > 2048)", max_L);
+    int K = ctc_lattice_shape(max_L, &W);
+    // label rows of more than 2048 states and alphabets of more than 256 symbols (the reference bounds neither,
+    // ctc_fast.pyx:22-32): the generic kernels of ctc_generic.hip
+    {
+        const char* gz = getenv("SCTC_CTC_GENERIC");
+        plan->generic = K == 0 || A > 256 || (gz && atoi(gz) != 0);
+    }
+    if (plan->generic) { K = 0; W = 0; }
     plan->B = B;
     plan->A = A;
     plan->blank = blank;
@@ -50,16 +56,35 @@ int ctc_make_plan(int B, int A, int blank, const int32_t* T_b, const int32_t* U_
     plan->W = W;
     {
         const char* lz = getenv("SCTC_CTC_LAZY");
-        plan->lazy = lz ? atoi(lz) : 0;
+        plan->lazy = (lz && !plan->generic) ? atoi(lz) : 0;
     }
-    plan->lp = 64 * W * K;
+    plan->lp = plan->generic ? (int)round_up(max_L + 1, 64) : 64 * W * K;
     plan->max_T = max_T;
-    plan->lat_elems = frames * plan->lp;
+    plan->frames = frames;
     plan->n_labels = n_labels;
+    // Rows of up to 256 states: both recursions and the gradient in ONE kernel that keeps one packed half lattice
+    // per direction (ctc_fused.hip).  SCTC_CTC_FUSED=0 runs the three-kernel path (A/B, tests); the lazy rescaling
+    // schedule exists there only.  Float32 probabilities keep their rows in the 32-bit format of ctc_fused.hip
+    // unless SCTC_CTC_STORE=64.
+    {
+        const char* fz = getenv("SCTC_CTC_FUSED");
+        const char* sb = getenv("SCTC_CTC_STORE");
+        plan->fused = !plan->generic && W == 1 && K <= 4 && !plan->lazy && (fz ? atoi(fz) != 0 : true);
+        plan->store_bytes = (dtype == SCTC_F32 && !(sb && atoi(sb) == 64)) ? 4 : 8;
+    }
+    const size_t head = align256(sizeof(CtcUtt) * B) + align256(sizeof(int32_t) * (2 * n_labels + (int64_t)B * (A + 1)));
+    if (plan->fused) {
+        int64_t elems = 0;
+        for (int b = 0; b < B; ++b) elems += K + (int64_t)T_b[b] * round_up(2 * U_b[b] + 1, K);
+        plan->lat_elems = elems;
+        plan->bytes = head + align256((size_t)plan->store_bytes * elems);
+        return SCTC_OK;
+    }
+    plan->lat_elems = frames * plan->lp;
     // labels, the same labels grouped by value (ctc_grad's per-label sums), group offsets
-    plan->bytes = align256(sizeof(CtcUtt) * B) + align256(sizeof(int32_t) * (2 * n_labels + (int64_t)B * (A + 1))) +
-                  align256(sizeof(double) * 2 * B) + align256(sizeof(int32_t) * 2 * B) +
-                  2 * align256(sizeof(double) * plan->lat_elems);
+    plan->bytes = head + align256(sizeof(double) * 2 * B) + align256(sizeof(int32_t) * 2 * B) +
+                  2 * align256(sizeof(double) * plan->lat_elems) +
+                  (plan->generic ? align256(sizeof(double) * 4 * (size_t)B * plan->lp) : 0);
     return SCTC_OK;
 }
 
@@ -84,10 +109,18 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
     CtcUtt* d_utts = ar.take<CtcUtt>(plan.B);
     const int64_t n_int = 2 * plan.n_labels + (int64_t)plan.B * (plan.A + 1);
     int32_t* d_labels = ar.take<int32_t>(n_int);
-    double* d_ll = ar.take<double>(2 * plan.B);
-    int32_t* d_skip2 = ar.take<int32_t>(2 * plan.B);
-    double* d_alpha = ar.take<double>(plan.lat_elems);
-    double* d_beta = ar.take<double>(plan.lat_elems);
+    double *d_ll = nullptr, *d_alpha = nullptr, *d_beta = nullptr, *d_scratch = nullptr;
+    int32_t* d_skip2 = nullptr;
+    char* d_store = nullptr;
+    if (plan.fused) {
+        d_store = ar.take<char>((size_t)plan.store_bytes * plan.lat_elems);
+    } else {
+        d_ll = ar.take<double>(2 * plan.B);
+        d_skip2 = ar.take<int32_t>(2 * plan.B);
+        d_alpha = ar.take<double>(plan.lat_elems);
+        d_beta = ar.take<double>(plan.lat_elems);
+        if (plan.generic) d_scratch = ar.take<double>(4 * (size_t)plan.B * plan.lp);
+    }
     if (ar.overflow)
         return set_error(SCTC_ERR_WORKSPACE, "ctc: workspace %zu bytes < %zu needed", ws_bytes,
                          ar.used);
@@ -104,7 +137,7 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
         u.T = bt->T_b[b];
         u.U = bt->U_b[b];
         u.row0 = bt->frame_off[b];
-        u.lat_off = lat_off;
+        u.lat_off = plan.fused ? lat_off + plan.K : lat_off;   // fused: K elements of pad in front (ctc_fused.hip)
         u.lab_off = lab_off;
         const int32_t* src = bt->labels + bt->label_off[b];
         for (int i = 0; i < u.U; ++i) {
@@ -121,7 +154,7 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
         for (int k = 0; k < plan.A; ++k) start[k + 1] += start[k];
         st.cursor.assign(start, start + plan.A);
         for (int i = 0; i < u.U; ++i) grouped[st.cursor[src[i]]++] = 2 * i + 1;
-        lat_off += (int64_t)u.T * plan.lp;
+        lat_off += plan.fused ? plan.K + (int64_t)u.T * round_up(2 * u.U + 1, plan.K) : (int64_t)u.T * plan.lp;
         lab_off += u.U;
     }
     const size_t utt_bytes = sizeof(CtcUtt) * plan.B, utt_span = align256(utt_bytes), lab_bytes = sizeof(int32_t) * n_int;
@@ -137,6 +170,25 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
         SCTC_HIP_TRY(hipMemcpyAsync(d_labels, labels.data(), lab_bytes, hipMemcpyHostToDevice, stream));
     }
 
+    if (plan.fused) {
+        CtcFusedArgs<R> fa;
+        fa.utts = d_utts;
+        fa.probs = probs;
+        fa.grad = grad;
+        fa.ld = bt->ld;
+        fa.A = plan.A;
+        fa.blank = plan.blank;
+        fa.rowbase = bt->rowbase_dev;
+        fa.labels = d_labels;
+        fa.by_label = d_labels + plan.n_labels;
+        fa.label_start = d_labels + 2 * plan.n_labels;
+        fa.store = d_store;
+        fa.cost = cost;
+        fa.skip = skip;
+        SCTC_TRY(launch_ctc_fused<R>(fa, plan.B, plan.K, plan.store_bytes, stream));
+        if (!keep) SCTC_HIP_TRY(hipStreamSynchronize(stream));
+        return SCTC_OK;
+    }
     CtcLatticeArgs<R> la;
     la.utts = d_utts;
     la.probs = probs;
@@ -150,7 +202,9 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
     la.beta = d_beta;
     la.ll = d_ll;
     la.skip2 = d_skip2;
-    SCTC_TRY(launch_ctc_lattice<R>(la, plan.B, plan.K, plan.W, sizeof(R) == 4 ? plan.lazy : 0, stream));
+    la.scratch = d_scratch;
+    if (!plan.generic)
+        SCTC_TRY(launch_ctc_lattice<R>(la, plan.B, plan.K, plan.W, sizeof(R) == 4 ? plan.lazy : 0, stream));
 
     CtcGradArgs<R> ga;
     ga.utts = d_utts;
@@ -171,7 +225,10 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
     ga.cost = cost;
     ga.skip = skip;
     ga.lazy = sizeof(R) == 4 ? plan.lazy : 0;
-    SCTC_TRY(launch_ctc_grad<R>(ga, plan.B, plan.max_T, stream));
+    if (plan.generic)
+        SCTC_TRY(launch_ctc_generic<R>(la, ga, plan.B, plan.max_T, stream));
+    else
+        SCTC_TRY(launch_ctc_grad<R>(ga, plan.B, plan.max_T, stream));
     // the pageable host staging must outlive the async copies
     if (!keep) SCTC_HIP_TRY(hipStreamSynchronize(stream));
     return SCTC_OK;
@@ -185,7 +242,7 @@ int ctc_run_batch(const sctc_ctc_batch* bt, const void* probs, void* grad, doubl
     SCTC_CHECK_ARG(bt->dtype == SCTC_F32 || bt->dtype == SCTC_F64, "ctc: bad dtype %d", bt->dtype);
     SCTC_CHECK_ARG(bt->ld >= bt->A, "ctc: ld %lld < A %d", (long long)bt->ld, bt->A);
     CtcPlan plan;
-    SCTC_TRY(ctc_make_plan(bt->B, bt->A, bt->blank, bt->T_b, bt->U_b, &plan));
+    SCTC_TRY(ctc_make_plan(bt->B, bt->A, bt->blank, bt->dtype, bt->T_b, bt->U_b, &plan));
     if (bt->dtype == SCTC_F32)
         return run_ctc<float>(bt, plan, (const float*)probs, (float*)grad, cost, skip, ws,
                               ws_bytes, stream, keep);
@@ -232,7 +289,7 @@ size_t sctc_ctc_workspace_bytes(const sctc_ctc_batch* bt)
 {
     if (!bt) return 0;
     CtcPlan plan;
-    if (ctc_make_plan(bt->B, bt->A, bt->blank, bt->T_b, bt->U_b, &plan) != SCTC_OK) return 0;
+    if (ctc_make_plan(bt->B, bt->A, bt->blank, bt->dtype, bt->T_b, bt->U_b, &plan) != SCTC_OK) return 0;
     return plan.bytes;
 }
 

@@ -1,0 +1,613 @@
+// CTC forward-backward with the gradient formed INSIDE the two recursions ("meet in the middle"):
+// the device counterpart of ctc_fast/ctc-loss/ctc_fast.pyx:13-152 for label rows of up to 256
+// lattice states (2U+1 <= 256: every shape of BASELINE configs[0..3]).
+//
+// One workgroup = one utterance = two waves: wave 0 runs the scaled alpha recursion
+// (ctc_fast.pyx:42-76), wave 1 the beta recursion (:79-114) as an alpha pass on the reversed
+// problem (ctc_kernels.hip, header).  With Ta = T/2:
+//
+//   phase 0   alpha walks t = 0 .. Ta-1, beta walks t = T-1 .. Ta; each STORES its normalised rows
+//   barrier   (the workgroup's own stores, same CU / same L2)
+//   phase 1   alpha walks t = Ta .. T-1 and at every frame multiplies its row -- still in
+//             registers -- with the beta row of the same frame stored in phase 0; beta walks
+//             t = Ta-1 .. 0 against the stored alpha rows.  Each wave forms ab = alpha*beta
+//             (:117-119), the per-label sums (:120-131), absum (:133-136) and the frame's
+//             gradient row (:138-145) and writes it: every frame's gradient is produced exactly
+//             once, by the wave whose recursion reaches it second.
+//
+// Against ctc_lattice_kernel + ctc_grad_kernel (both lattices stored in float64 over a 64K-wide
+// row, both read back by a third kernel: 4 lattice passes over HBM) a lattice element is stored
+// at most once and read at most once, rows are packed to round_up(2U+1, K) states, and the read
+// happens in the workgroup that wrote it (the row is in that XCD's L2 unless the batch is so
+// large that it has been evicted).  Rounds 1-4 stored 2 x 8 x 256 bytes per frame and direction
+// at cfg-3; this kernel stores 4 x 204 per frame and ONE direction.
+//
+// Storage type ST of the kept rows:
+//   double    float64 probabilities (the ctc_fast.ctc_loss host signature): nothing is rounded;
+//   uint32_t  float32 probabilities (the BRNN path): the row is normalised, every value lies in
+//             [0, 1] (+ an ulp), so the sign bit and the top exponent bit of the float64 pattern
+//             are always zero: bits 61..30 are kept, rounded to nearest -- 10 exponent bits (the
+//             FULL float64 range below 2.0) and 22 mantissa bits (float32 has 23).  A plain
+//             float32 copy would NOT do: at T >> 2U the states where alpha and beta overlap carry
+//             1e-40 .. 1e-300 of a frame's mass (random inputs, T = 1000, U = 100: gradient error
+//             1.0 with float32 rows, 4e-8 with this format -- below the quantum of the float32
+//             gradient it is written to; tests/test_ctc_store_model.py restates the experiment).
+//             SCTC_CTC_STORE=64 keeps float64 rows on the float32 path too (A/B, tests).
+// The recursion itself, the normalisers and llForward stay float64 like the reference.
+//
+// Summation order.  absum[t] divides every state's product by ITS label's probability before it
+// sums (:125-131): that order is kept (the per-label form sum_k g_k / y_k is the same number until
+// the products are denormal -- then it is off by 1e-3, and the reference's value is what
+// counts).  The division is a multiplication with the correctly rounded reciprocal, computed once
+// per label state and block of frames, off the recursion's dependency chain.  The sums themselves
+// are taken as fixed trees (bit-reproducible run to run; the reference adds in ascending state
+// order: differences are in the last bits, the float64 golden vectors hold at 1e-11 / 1e-9).
+#include <type_traits>
+
+#include "common.h"
+#include "ctc_kernels.h"
+#include "xlane.h"
+
+namespace sctc {
+
+namespace {
+
+template <typename ST>
+struct Store;
+template <>
+struct Store<double> {
+    static __device__ __forceinline__ double enc(double x) { return x; }
+    static __device__ __forceinline__ double dec(double s) { return s; }
+};
+template <>
+struct Store<uint32_t> {
+    static __device__ __forceinline__ uint32_t enc(double x)
+    {
+        return (uint32_t)(((uint64_t)__double_as_longlong(x) + (1ull << 29)) >> 30);
+    }
+    static __device__ __forceinline__ double dec(uint32_t s)
+    {
+        return __longlong_as_double((long long)((uint64_t)s << 30));
+    }
+};
+
+// K stored states as one memory block; the reader's block is K-element contiguous but only
+// element-aligned (it mirrors the writer's lane order), so the type promises no more than that
+template <typename ST, int K>
+struct __attribute__((packed, aligned(sizeof(ST)))) RowBlockU {
+    ST v[K];
+};
+template <typename ST, int K>
+struct __attribute__((aligned(sizeof(ST) * K))) RowBlockA {
+    ST v[K];
+};
+
+}  // namespace
+
+template <typename RI, typename ST, int K, int NA>
+__global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
+{
+    using R = double;
+    static_assert(K == 2 || K == 4, "one wave per direction: 2 or 4 states per lane");
+    constexpr int KH = K / 2;
+    // Frames per block: the probabilities (and, phase 1, the other direction's rows) of a block are
+    // prefetched a block ahead, a block's rows are stored / its gradient rows finished behind its last
+    // frame, so that the frames themselves are ONE basic block without a store or a branch: whatever
+    // does not feed the recursion is scheduled into the gaps of its dependency chain.
+    constexpr int PF = 8;
+    constexpr int NI = NA == 1 ? 8 : 4;     // list entries of a label kept in registers
+    constexpr int NPOS = 64 * KH;           // label positions of one direction; slot NPOS holds 0.0
+    constexpr int LSTR = NPOS + 2;
+    constexpr int RSTR = 66;                // row stride of the reduction scratch (bank spread)
+    using BlkU = RowBlockU<ST, K>;
+    using BlkA = RowBlockA<ST, K>;
+
+    __shared__ __attribute__((aligned(16))) double lab_s[2][PF][LSTR];   // alpha*beta of the label states, per frame of a block
+    __shared__ __attribute__((aligned(16))) double red_s[2][2 * PF][RSTR];
+    __shared__ int32_t ord_pos[2][NPOS];
+    __shared__ int32_t sh_skip[2];
+    __shared__ double sh_cost;
+
+    const int b = blockIdx.x;
+    const int dir = threadIdx.x >> 6;   // 0: alpha, 1: beta (== alpha of the reversed problem)
+    const int lane = threadIdx.x & 63, gl = lane;
+    const CtcUtt u = p.utts[b];
+    const int T = u.T, U = u.U, L = 2 * U + 1;
+    const int stride = (L + K - 1) / K * K;
+    const int Ta = T / 2, Tb = T - Ta;
+    const int Tst = dir ? Tb : Ta;      // my stored rows: tau in [0, Tst)
+    ST* mine = reinterpret_cast<ST*>(p.store) + u.lat_off + (dir ? (int64_t)Ta * stride : 0);
+    const ST* other = reinterpret_cast<const ST*>(p.store) + u.lat_off + (dir ? 0 : (int64_t)Ta * stride);
+    const int32_t* seq = p.labels + u.lab_off;
+    const int blank = p.blank;
+    const int A = p.A;
+    const RI* probs = p.probs;
+    RI* grad = p.grad;
+    const int64_t ld = p.ld;
+
+    // ---- per-lane constants: labels of my odd states, skip-transition permission (ctc_lattice_kernel)
+    int lab[KH];
+    bool allow[KH], valid_lab[KH], valid_blk[KH];
+    R allowf[KH];
+#pragma unroll
+    for (int jj = 0; jj < KH; ++jj) {
+        const int idx = KH * gl + jj;
+        const bool ok = idx < U;
+        const int i0 = ok ? (dir ? U - 1 - idx : idx) : 0;
+        lab[jj] = seq[i0];
+        int prev = blank;
+        if (ok && idx >= 1) prev = seq[dir ? U - idx : idx - 1];
+        allow[jj] = ok && idx >= 1 && lab[jj] != prev;   // ctc_fast.pyx:64-68 / :103-107
+        allowf[jj] = allow[jj] ? (R)1 : (R)0;
+        valid_lab[jj] = ok;
+        valid_blk[jj] = idx <= U;
+    }
+    // my states that exist (the other direction's block is read mirrored and runs past the row's
+    // first element in the lane that holds state L-1)
+    bool inrow[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) inrow[j] = K * gl + j < L;
+    const bool store_lane = K * gl < stride;
+    const bool orow_lane = K * gl < L;
+
+    // ---- gradient side: lane k (+64q) owns label k's list of label positions, in MY direction's order
+    int lidx[NA][NI];
+    int llen[NA], lj0[NA];
+    int maxlen = 0;
+    {
+        const int32_t* start = p.label_start + (int64_t)b * (A + 1);
+        const int32_t* byl = p.by_label + u.lab_off;
+        for (int j = lane; j < U; j += 64) {
+            const int i = byl[j] >> 1;                    // by_label holds states 2i+1
+            ord_pos[dir][j] = dir ? U - 1 - i : i;
+        }
+        if (lane < PF) {
+            lab_s[dir][lane][NPOS] = 0.0;
+            lab_s[dir][lane][NPOS + 1] = 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int k = lane + 64 * q;
+            const int j0 = k < A ? start[k] : 0, j1 = k < A ? start[k + 1] : 0;
+            lj0[q] = j0;
+            llen[q] = j1 - j0;
+            maxlen = max(maxlen, llen[q]);
+#pragma unroll
+            for (int n = 0; n < NI; ++n) lidx[q][n] = n < llen[q] ? ord_pos[dir][j0 + n] : NPOS;
+        }
+        maxlen = wave_max(maxlen);
+    }
+
+    auto load_row = [&](int64_t row, RI (&dst)[NA]) {
+        const RI* yr = probs + row * ld;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int k = lane + 64 * q;
+            dst[q] = k < A ? yr[k] : (RI)0;
+        }
+    };
+    auto block_rows = [&](int tau0) -> int {
+        const int tau = min(tau0 + lane, T - 1);
+        const int t = dir ? T - 1 - tau : tau;
+        return (p.rowbase ? p.rowbase[t] : t);
+    };
+    auto gather = [&](const RI (&y)[NA], int k) -> R {
+        RI out = lane_gather(y[0], k & 63);
+#pragma unroll
+        for (int q = 1; q < NA; ++q) {
+            RI o = lane_gather(y[q], k & 63);
+            if ((k >> 6) == q) out = o;
+        }
+        return (R)out;   // probs.astype(np.float64), brnnet.py:175
+    };
+    auto bcast = [&](const RI (&y)[NA], int k) -> R {
+        RI out = lane_bcast(y[0], k & 63);
+#pragma unroll
+        for (int q = 1; q < NA; ++q) {
+            RI o = lane_bcast(y[q], k & 63);
+            if ((k >> 6) == q) out = o;
+        }
+        return (R)out;
+    };
+    // the other direction's row of MY frame tau: its own time index is T-1-tau, its state order mine mirrored
+    auto load_other = [&](int tau, BlkU& dst) {
+        const int taup = T - 1 - min(tau, T - 1);
+        if (orow_lane) {
+            dst = *reinterpret_cast<const BlkU*>(other + (int64_t)taup * stride + (L - K * (gl + 1)));
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; ++j) dst.v[j] = (ST)0;
+        }
+    };
+    auto recip = [&](R c) -> R {   // ctc_lattice_kernel: hardware estimate + two Newton-Raphson steps (<= 1 ulp)
+        R x = __builtin_amdgcn_rcp(c);
+        R e = fma(-c, x, (R)1);
+        x = fma(x, e, x);
+        e = fma(-c, x, (R)1);
+        return fma(x, e, x);
+    };
+    // 1/y for absum's per-state division (:125-131); y == 0 only ever meets a product that is exactly zero
+    // (the reference's `ab != 0` guard).  float32 probabilities are normal float64 numbers: the Newton
+    // reciprocal; float64 probabilities may be denormal: the IEEE division.
+    auto recip_or_zero = [&](R y) -> R {
+        if constexpr (sizeof(RI) == 4) {
+            const R r = recip(y);
+            return y > (R)0 ? r : (R)0;
+        } else {
+            return y > (R)0 ? (R)1 / y : (R)0;
+        }
+    };
+    auto local_sum = [&](const R (&n)[K]) -> R {
+        if constexpr (K == 2) return n[0] + n[1];
+        else return (n[0] + n[1]) + (n[2] + n[3]);
+    };
+    auto quad_xor = [&](R v, auto ctrl_tag) -> R {
+        constexpr int CTRL = decltype(ctrl_tag)::value;
+        long long bits = __double_as_longlong(v);
+        int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xffffffffll), CTRL, 0xF, 0xF, true);
+        int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xF, 0xF, true);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    };
+
+    R a[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) a[j] = (R)0;
+    constexpr int NO_BAD = 0x7fffffff;
+    int first_bad = NO_BAD;
+    int skip = 0;
+    // llForward = sum_t log c_t (ctc_fast.pyx:47,76) = -log of the product of the applied factors r_t = 1/c_t:
+    // the product is carried as mantissa x 2^exponent (three operations per frame, beside the recursion's
+    // chain) and its logarithm taken once; frames from the first zero band sum on do not count (the
+    // reference's exception leaves llForward as it was, :147-149)
+    R ll_m = (R)1;
+    int ll_e = 0;
+    auto ll_account = [&](R r) {
+        const R f = first_bad == NO_BAD ? r : (R)1;
+        ll_m *= f;
+        ll_e += __builtin_amdgcn_frexp_exp(ll_m);
+        ll_m = __builtin_amdgcn_frexp_mant(ll_m);
+    };
+    // T < U: empty band at every frame t >= 1 -- the reference divides nothing, adds log(0) and
+    // returns cost +inf, grad = params, skip False (ctc_fast.pyx:70-76 on an empty range)
+    const bool empty_band = (L >= 2 * T + 2) && T > 1;
+
+    // one frame of the recursion; FAST: the band starts at state 0 (no band tests, ctc_lattice_kernel)
+    auto step = [&](auto fast_tag, int tau, R yb, const R (&yl)[KH]) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const R prev_last = lane_shr1(a[K - 1]);
+        R n[K];
+        if constexpr (FAST) {
+#pragma unroll
+            for (int jj = 0; jj < KH; ++jj) {
+                const R below = jj == 0 ? prev_last : a[2 * jj - 1];
+                n[2 * jj] = (a[2 * jj] + below) * yb;
+                n[2 * jj + 1] = fma(below, allowf[jj], a[2 * jj + 1] + a[2 * jj]) * yl[jj];
+            }
+        } else {
+            // lower band limit, ctc_fast.pyx:49-53; states >= end are exactly zero by construction
+            const int rem = 2 * (T - tau);
+            const int start = L <= rem ? 0 : L - rem;
+#pragma unroll
+            for (int jj = 0; jj < KH; ++jj) {
+                const R below = jj == 0 ? prev_last : a[2 * jj - 1];
+                const int sb = K * gl + 2 * jj;
+                const R vb = (a[2 * jj] + below) * yb;                 // :58-62
+                n[2 * jj] = (valid_blk[jj] && sb >= start) ? vb : (R)0;
+                R in = a[2 * jj + 1] + a[2 * jj];                      // :63-68
+                if (allow[jj]) in += below;
+                const R vl = in * yl[jj];
+                n[2 * jj + 1] = (valid_lab[jj] && sb + 1 >= start) ? vl : (R)0;
+            }
+        }
+        const R c = wave_sum(local_sum(n));
+        R r;
+        if constexpr (FAST) {
+            first_bad = (c == (R)0 && first_bad == NO_BAD) ? tau : first_bad;   // ZeroDivisionError at :75
+            r = recip(c);
+        } else {
+            first_bad = (c == (R)0 && !empty_band && first_bad == NO_BAD) ? tau : first_bad;
+            r = empty_band ? (R)1 : recip(c);
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) a[j] = n[j] * r;
+        ll_account(r);
+    };
+    // phase 1, inside the frame: alpha*beta of my states against the other direction's stored row;
+    // label products to the frame's LDS slot, the lane's share of absum[t] (zl) and of the blank sum (eb)
+    auto products = [&](int slot, const BlkU& ob, R rb, const R (&rl)[KH], R& zl, R& eb) {
+        R ab[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const R o = Store<ST>::dec(ob.v[K - 1 - j]);
+            ab[j] = a[j] * (inrow[j] ? o : (R)0);                       // :119
+        }
+        R z = (R)0, e = (R)0;
+#pragma unroll
+        for (int jj = 0; jj < KH; ++jj) {
+            e += ab[2 * jj];                                             // blank states, :122-124
+            z = fma(ab[2 * jj], rb, z);                                  // :125-126
+            z = fma(ab[2 * jj + 1], rl[jj], z);                          // :130-131
+        }
+        zl = z;
+        eb = e;
+        if constexpr (KH == 2) {
+            *reinterpret_cast<double2*>(&lab_s[dir][slot][2 * gl]) = make_double2(ab[1], ab[3]);
+        } else {
+            lab_s[dir][slot][gl] = ab[1];
+        }
+    };
+    // phase 1, behind a block's frames: absum and the blank sum of its PF frames (2 PF sums over the wave,
+    // transposed through LDS: lane -> (sum, quarter) instead of 2 PF wave reductions), the per-label sums
+    // (:120-131) from the frames' LDS slots, the gradient rows (:138-145)
+    auto finish_block = [&](int tb, int t_end, const RI (&yc)[PF][NA], int rows, const R (&zl)[PF], const R (&eb)[PF]) {
+        static_assert(2 * PF * 4 == 64, "one lane per (sum, quarter)");
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            red_s[dir][i][lane] = zl[i];
+            red_s[dir][PF + i][lane] = eb[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        R tot;
+        {
+            const double2* src = reinterpret_cast<const double2*>(&red_s[dir][lane >> 2][(lane & 3) * 16]);
+            double2 v[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) v[n] = src[n];
+            R s[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) s[n] = v[n].x + v[n].y;
+            tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+            tot += quad_xor(tot, std::integral_constant<int, 0xB1>());   // quad_perm [1,0,3,2]
+            tot += quad_xor(tot, std::integral_constant<int, 0x4E>());   // quad_perm [2,3,0,1]
+        }
+        R g[PF][NA];
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                R v[NI];
+#pragma unroll
+                for (int n = 0; n < NI; ++n) v[n] = lab_s[dir][i][lidx[q][n]];
+#pragma unroll
+                for (int w = 1; w < NI; w *= 2)
+#pragma unroll
+                    for (int n = 0; n + w < NI; n += 2 * w) v[n] += v[n + w];
+                g[i][q] = v[0];
+            }
+        if (maxlen > NI) {   // a label with more than NI positions (uniform): the rest of every list
+#pragma unroll
+            for (int q = 0; q < NA; ++q)
+                for (int n = NI; n < maxlen; ++n) {
+                    const int pos = n < llen[q] ? ord_pos[dir][lj0[q] + n] : NPOS;
+#pragma unroll
+                    for (int i = 0; i < PF; ++i) g[i][q] += lab_s[dir][i][pos];
+                }
+        }
+        RI out[PF][NA];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const R Z = lane_bcast(tot, 4 * i);                          // absum[t], :133-136
+            const R gb = lane_bcast(tot, 4 * (PF + i));
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int k = lane + 64 * q;
+                const R gk = k == blank ? g[i][q] + gb : g[i][q];
+                const R y = (R)yc[i][q];
+                const R tmp = y * Z;                                     // :141
+                out[i][q] = (RI)(tmp > (R)0 ? y - gk / tmp : y);         // :142-145 (cast: brnnet.py:188)
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int k = lane + 64 * q;
+            if (k < A) {
+#pragma unroll
+                for (int i = 0; i < PF; ++i)
+                    if (tb + i < t_end)
+                        grad[((int64_t)__builtin_amdgcn_readlane(rows, i) + u.row0) * ld + k] = out[i][q];
+            }
+        }
+        // the next block's products overwrite the slots: LDS executes a wave's accesses in order, the
+        // compiler must keep them in order too
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // ---- frames [t_begin, t_end) of my direction; PH 0: store the rows, PH 1: form the gradient
+    auto run = [&](auto ph_tag, int t_begin, int t_end) {
+        constexpr int PH = decltype(ph_tag)::value;
+        if (skip || t_begin >= t_end) return;
+        RI ycur[PF][NA];
+        BlkU ocur[PH ? PF : 1];
+        int rb_cur = block_rows(t_begin);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            load_row((int64_t)__builtin_amdgcn_readlane(rb_cur, i) + u.row0, ycur[i]);
+            if constexpr (PH) load_other(t_begin + i, ocur[i]);
+        }
+        int rb_nxt = block_rows(t_begin + PF);
+        for (int tb = t_begin; tb < t_end && !skip; tb += PF) {
+            RI ynxt[PF][NA];
+            BlkU onxt[PH ? PF : 1];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                load_row((int64_t)__builtin_amdgcn_readlane(rb_nxt, i) + u.row0, ynxt[i]);
+                if constexpr (PH) load_other(tb + PF + i, onxt[i]);
+            }
+            const int rb_next2 = block_rows(tb + 2 * PF);
+            // the block's probabilities per state, gathered before the serial part starts
+            R ybv[PF], ylv[PF][KH];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                ybv[i] = bcast(ycur[i], blank);
+#pragma unroll
+                for (int jj = 0; jj < KH; ++jj) {
+                    const R g = gather(ycur[i], lab[jj]);
+                    ylv[i][jj] = valid_lab[jj] ? g : (R)0;
+                }
+            }
+            BlkA enc[PH ? 1 : PF];
+            R zl[PH ? PF : 1], eb[PH ? PF : 1];
+            auto post = [&](int i) {
+                if constexpr (PH) {
+                    R rl[KH];
+#pragma unroll
+                    for (int jj = 0; jj < KH; ++jj) rl[jj] = recip_or_zero(ylv[i][jj]);
+                    products(i, ocur[i], recip_or_zero(ybv[i]), rl, zl[i], eb[i]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < K; ++j) enc[i].v[j] = Store<ST>::enc(a[j]);
+                }
+            };
+            const bool fast = (tb + PF - 1 < t_end) && (L <= 2 * (T - (tb + PF - 1)));
+            if (fast) {
+#pragma unroll
+                for (int i = 0; i < PF; ++i) {
+                    step(std::true_type(), tb + i, ybv[i], ylv[i]);
+                    post(i);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < PF; ++i) {
+                    if (tb + i < t_end) {
+                        step(std::false_type(), tb + i, ybv[i], ylv[i]);
+                        post(i);
+                    } else if constexpr (PH) {
+                        zl[i] = (R)0;
+                        eb[i] = (R)0;
+                    }
+                }
+            }
+            if constexpr (PH) {
+                finish_block(tb, t_end, ycur, rb_cur, zl, eb);
+            } else {
+                if (store_lane) {
+#pragma unroll
+                    for (int i = 0; i < PF; ++i)
+                        if (tb + i < t_end)
+                            *reinterpret_cast<BlkA*>(mine + (int64_t)(tb + i) * stride + K * gl) = enc[i];
+                }
+            }
+            if (first_bad != NO_BAD) skip = 1;
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+#pragma unroll
+                for (int q = 0; q < NA; ++q) ycur[i][q] = ynxt[i][q];
+                if constexpr (PH) ocur[i] = onxt[i];
+            }
+            rb_cur = rb_nxt;
+            rb_nxt = rb_next2;
+        }
+    };
+
+    // ---- tau = 0 (ctc_fast.pyx:42-47 / :79-84); it belongs to phase 1 only when T == 1 (alpha stores nothing)
+    {
+        RI y0[NA];
+        const int t = dir ? T - 1 : 0;
+        const int64_t row0 = (int64_t)(p.rowbase ? p.rowbase[t] : t) + u.row0;
+        load_row(row0, y0);
+        const R yb = bcast(y0, blank);
+        const R yl = gather(y0, lab[0]);
+        if (gl == 0) { a[0] = yb; a[1] = yl; }
+        const R c = wave_sum(a[0] + a[1]);
+        if (c == (R)0) {
+            skip = 1;   // ZeroDivisionError at :45
+            first_bad = 0;
+        } else {
+            const R r = recip(c);
+            a[0] *= r;
+            a[1] *= r;
+            ll_account(r);
+        }
+        if (Tst > 0 && store_lane) {
+            BlkA blk;
+#pragma unroll
+            for (int j = 0; j < K; ++j) blk.v[j] = Store<ST>::enc(a[j]);
+            *reinterpret_cast<BlkA*>(mine + K * gl) = blk;
+        }
+    }
+    run(std::integral_constant<int, 0>(), 1, Tst);
+    __syncthreads();   // phase 0 rows of both directions are in L2 (vmcnt(0) + barrier; same CU)
+    if (Tst == 0 && !skip) {
+        // T == 1, alpha: the one frame's gradient against beta's stored row 0
+        RI yc[PF][NA];
+        const int rows = p.rowbase ? p.rowbase[0] : 0;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) load_row((int64_t)rows + u.row0, yc[i]);
+        BlkU ob;
+        load_other(0, ob);
+        R rl[KH], zl[PF], eb[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) { zl[i] = (R)0; eb[i] = (R)0; }
+#pragma unroll
+        for (int jj = 0; jj < KH; ++jj) {
+            const R g = gather(yc[0], lab[jj]);
+            rl[jj] = recip_or_zero(valid_lab[jj] ? g : (R)0);
+        }
+        products(0, ob, recip_or_zero(bcast(yc[0], blank)), rl, zl[0], eb[0]);
+        finish_block(0, 1, yc, rows, zl, eb);
+    }
+    run(std::integral_constant<int, 1>(), Tst > 0 ? Tst : 1, T);
+
+    if (dir == 0 && lane == 0) {
+        // -llForward (ctc_fast.pyx:149,152); math.log(0.0) for the empty band
+        double cost = log(ll_m) + (double)ll_e * 0.693147180559945309417232121458;
+        if (empty_band && !skip) cost = INFINITY;
+        sh_cost = cost;
+    }
+    if (lane == 0) sh_skip[dir] = skip;
+    __syncthreads();
+    const int any_skip = sh_skip[0] | sh_skip[1];
+    if (threadIdx.x == 0) {
+        p.cost[b] = sh_cost;
+        p.skip[b] = any_skip;
+    }
+    if (any_skip) {
+        // the reference returns its zero-initialised grad (ctc_fast.pyx:31-32,149): rows written before
+        // the failing frame was reached are taken back
+        for (int t = dir; t < T; t += 2) {
+            RI* gr = grad + ((int64_t)(p.rowbase ? p.rowbase[t] : t) + u.row0) * ld;
+            for (int k = lane; k < A; k += 64) gr[k] = (RI)0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- launcher
+
+template <typename RI, typename ST, int K>
+static int launch_fused_k(const CtcFusedArgs<RI>& a, int B, int NA, hipStream_t stream)
+{
+    dim3 grid(B), block(128);
+    if (NA == 1) hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, 1>), grid, block, 0, stream, a);
+    else if (NA == 2) hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, 2>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, 4>), grid, block, 0, stream, a);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+template <typename RI>
+int launch_ctc_fused(const CtcFusedArgs<RI>& a, int B, int K, int store_bytes, hipStream_t stream)
+{
+    const int NA = a.A <= 64 ? 1 : (a.A <= 128 ? 2 : 4);
+    if constexpr (sizeof(RI) == 4) {
+        if (store_bytes == 4) {
+            if (K == 2) return launch_fused_k<RI, uint32_t, 2>(a, B, NA, stream);
+            if (K == 4) return launch_fused_k<RI, uint32_t, 4>(a, B, NA, stream);
+        }
+    }
+    if (store_bytes == 8) {
+        if (K == 2) return launch_fused_k<RI, double, 2>(a, B, NA, stream);
+        if (K == 4) return launch_fused_k<RI, double, 4>(a, B, NA, stream);
+    }
+    return set_error(SCTC_ERR_ARG, "ctc: no fused kernel for K=%d, %d-byte rows", K, store_bytes);
+}
+
+template int launch_ctc_fused<float>(const CtcFusedArgs<float>&, int, int, int, hipStream_t);
+template int launch_ctc_fused<double>(const CtcFusedArgs<double>&, int, int, int, hipStream_t);
+
+}  // namespace sctc

@@ -1,0 +1,256 @@
+// CTC forward-backward for shapes the register-resident kernels do not cover: label rows of more
+// than 2048 lattice states (2U+1 > 2048) and alphabets of more than 256 symbols.  The reference has
+// neither bound (ctc_fast/ctc-loss/ctc_fast.pyx:22-32 allocates (2U+1) x T per call, :24 takes the
+// alphabet from params.shape[0]); rounds 1-4 rejected both.  Nothing here depends on L or A at
+// compile time and nothing is held in registers or LDS across frames: slow (one workgroup barrier
+// and three L2 round trips per frame, about 2-3 us), correct, unbounded.  SCTC_CTC_GENERIC=1 routes
+// every shape here (tests: the golden vectors through these kernels).
+//
+//   ctc_lattice_generic   one workgroup per (utterance, direction); beta = alpha of the reversed
+//                         problem like ctc_lattice_kernel.  The UNNORMALISED row of a frame lives in
+//                         one of two scratch rows in global memory; the next frame reads it back through
+//                         L2 (agent-scope loads: the per-CU cache may hold what the row held two frames
+//                         ago) and applies the frame's factor on the way in -- the product n*r is the very
+//                         number the normalised row holds.  The normalised row + its factor go to the
+//                         lattice in the layout ctc_grad reads ([T][lp], factor in column lp-1).
+//   ctc_grad_generic      one workgroup per frame: absum and the blank sum as block reductions, every
+//                         other label's sum along its host-built list of states (ascending, the
+//                         reference's order, ctc_fast.pyx:120-131).
+//   softmax_rows_generic  three passes over a row of any width.
+#include "common.h"
+#include "ctc_kernels.h"
+#include "xlane.h"
+
+namespace sctc {
+
+namespace {
+
+constexpr int GEN_NT = 512;   // threads per lattice workgroup
+constexpr int GEN_NW = GEN_NT / 64;
+
+__device__ __forceinline__ double ld_l2(const double* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int64_t gen_frame_row(const CtcUtt& u, const int32_t* rowbase, int t)
+{
+    return rowbase ? (int64_t)rowbase[t] + u.row0 : u.row0 + t;
+}
+
+__device__ __forceinline__ double gen_recip(double c)   // ctc_lattice_kernel's reciprocal
+{
+    double x = __builtin_amdgcn_rcp(c);
+    double e = fma(-c, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-c, x, 1.0);
+    return fma(x, e, x);
+}
+
+// sum over the workgroup, identical in every thread, fixed order; `slot` alternates by caller
+template <int NW>
+__device__ __forceinline__ double block_sum_fixed(double v, double* red)
+{
+    const double ws = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += red[w];
+    return t;
+}
+
+}  // namespace
+
+template <typename RI>
+__global__ __launch_bounds__(GEN_NT) void ctc_lattice_generic_kernel(CtcLatticeArgs<RI> p)
+{
+    __shared__ double red[2][GEN_NW];
+    const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const CtcUtt u = p.utts[b];
+    const int T = u.T, U = u.U, L = 2 * U + 1, LP = p.lp;
+    double* lat = (dir == 0 ? p.alpha : p.beta) + u.lat_off;
+    double* sc = p.scratch + (int64_t)(2 * b + dir) * 2 * LP;
+    const int32_t* seq = p.labels + u.lab_off;
+    const int blank = p.blank;
+    // label of the odd state s of MY direction's row (beta: the reversed label sequence)
+    auto label_at = [&](int s) -> int {
+        const int i = (s - 1) >> 1;
+        return seq[dir ? U - 1 - i : i];
+    };
+    auto probs_row = [&](int tau) -> const RI* {
+        const int t = dir ? T - 1 - tau : tau;
+        return p.probs + gen_frame_row(u, p.rowbase, t) * p.ld;
+    };
+    const bool empty_band = (L >= 2 * T + 2) && T > 1;   // ctc_lattice_kernel: cost +inf, skip False
+
+    int skip = 0, n_rows = T;
+    double rprev = 1.0;
+    // ---- tau = 0 (ctc_fast.pyx:42-47 / :79-84)
+    {
+        const RI* y = probs_row(0);
+        const double a0 = (double)y[blank], a1 = (double)y[label_at(1)];
+        const double c = a0 + a1;
+        if (c == 0.0) {
+            skip = 1;   // ZeroDivisionError at :45
+            n_rows = 0;
+        } else {
+            rprev = gen_recip(c);
+        }
+        for (int s = tid; s < L; s += GEN_NT) {
+            const double v = s == 0 ? a0 : (s == 1 ? a1 : 0.0);
+            sc[s] = v;
+            lat[s] = v * rprev;
+        }
+        if (tid == 0) lat[LP - 1] = rprev;
+    }
+    __syncthreads();
+    for (int tau = 1; tau < T && !skip; ++tau) {
+        const double* prev = sc + (int64_t)((tau - 1) & 1) * LP;
+        double* cur = sc + (int64_t)(tau & 1) * LP;
+        const RI* y = probs_row(tau);
+        const double yb = (double)y[blank];
+        // lower band limit, ctc_fast.pyx:49-53; states >= end come out as exact zeros
+        const int rem = 2 * (T - tau);
+        const int start = L <= rem ? 0 : L - rem;
+        double part = 0.0;
+        for (int s = tid; s < L; s += GEN_NT) {
+            double v = 0.0;
+            if (s >= start) {
+                const double p0 = ld_l2(prev + s) * rprev;
+                const double p1 = s >= 1 ? ld_l2(prev + s - 1) * rprev : 0.0;
+                if ((s & 1) == 0) {
+                    v = (p0 + p1) * yb;                                        // :58-62
+                } else {
+                    const int lab = label_at(s);
+                    double in = p0 + p1;                                       // :63-68
+                    if (s >= 3 && lab != label_at(s - 2)) in += ld_l2(prev + s - 2) * rprev;
+                    v = in * (double)y[lab];
+                }
+            }
+            cur[s] = v;
+            part += v;
+        }
+        const double c = block_sum_fixed<GEN_NW>(part, red[tau & 1]);   // (barrier: the row is in L2)
+        double r = 1.0;
+        if (!empty_band) {
+            if (c == 0.0) {   // ZeroDivisionError at :75
+                skip = 1;
+                n_rows = tau;
+                break;
+            }
+            r = gen_recip(c);
+        }
+        double* row = lat + (int64_t)tau * LP;
+        for (int s = tid; s < L; s += GEN_NT) row[s] = ld_l2(cur + s) * r;
+        if (tid == 0) row[LP - 1] = r;
+        rprev = r;
+    }
+    // llForward = sum_t log c_t = - sum of log over the stored factors (ctc_lattice_kernel's order)
+    __syncthreads();
+    if (tid < 64) {
+        double ll = 0.0;
+        for (int tau = tid; tau < n_rows; tau += 64) ll -= log(ld_l2(lat + (int64_t)tau * LP + (LP - 1)));
+        double total = wave_sum(ll);
+        if (tid == 0) {
+            if (empty_band && !skip) total = -INFINITY;
+            p.ll[2 * b + dir] = total;
+            p.skip2[2 * b + dir] = skip;
+        }
+    }
+}
+
+template <typename RI>
+__global__ __launch_bounds__(256) void ctc_grad_generic_kernel(CtcGradArgs<RI> p)
+{
+    __shared__ double red[2][4];
+    const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    const CtcUtt u = p.utts[b];
+    const int T = u.T, U = u.U, L = 2 * U + 1, LP = p.lp, A = p.A, blank = p.blank;
+    if (t >= T) return;
+    const int skip = p.skip2[2 * b] | p.skip2[2 * b + 1];
+    if (t == 0 && tid == 0) {
+        p.cost[b] = -p.ll[2 * b];   // -llForward, ctc_fast.pyx:149,152
+        p.skip[b] = skip;
+    }
+    const int64_t row = gen_frame_row(u, p.rowbase, t);
+    const RI* y = p.probs + row * p.ld;
+    RI* gr = p.grad + row * p.ld;
+    if (skip) {   // the reference's zero-initialised grad (ctc_fast.pyx:31-32,149)
+        for (int k = tid; k < A; k += 256) gr[k] = (RI)0;
+        return;
+    }
+    const int32_t* seq = p.labels + u.lab_off;
+    const double* al = p.alpha + u.lat_off + (int64_t)t * LP;
+    const double* be = p.beta + u.lat_off + (int64_t)(T - 1 - t) * LP;   // stored reversed in t and s
+    const double yb = (double)y[blank];
+    double zpart = 0.0, bpart = 0.0;
+    for (int s = tid; s < L; s += 256) {
+        const double ab = al[s] * be[L - 1 - s];                              // :119
+        double v = ab;
+        if ((s & 1) == 0) {
+            bpart += ab;                                                      // :122-124
+            if (ab != 0.0) v = ab / yb;                                       // :125-126
+        } else {
+            if (ab != 0.0) v = ab / (double)y[seq[(s - 1) >> 1]];             // :130-131
+        }
+        zpart += v;
+    }
+    const double Z = block_sum_fixed<4>(zpart, red[0]);                       // absum[t], :133-136
+    const double gb = block_sum_fixed<4>(bpart, red[1]);
+    const int32_t* byl = p.by_label + u.lab_off;
+    const int32_t* start = p.label_start + (int64_t)b * (A + 1);
+    for (int k = tid; k < A; k += 256) {
+        double g = 0.0;
+        for (int j = start[k]; j < start[k + 1]; ++j) {
+            const int s = byl[j];
+            g += al[s] * be[L - 1 - s];
+        }
+        if (k == blank) g += gb;
+        const double yk = (double)y[k];
+        const double tmp = yk * Z;                                            // :141
+        gr[k] = (RI)(tmp > 0.0 ? yk - g / tmp : yk);                          // :142-145
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_generic_kernel(const float* __restrict__ x,
+                                                                   float* __restrict__ y, int64_t rows,
+                                                                   int A, int64_t ld)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ld;
+    float* yr = y + row * ld;
+    float m = -INFINITY;
+    for (int k = lane; k < A; k += 64) m = fmaxf(m, xr[k]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int k = lane; k < A; k += 64) s += expf(xr[k] - m);
+    s = wave_sum(s);
+    const float inv = 1.0f / s;   // cm.pow(rowVec,-1) then mult_by_row, brnnet.py:167-168
+    for (int k = lane; k < A; k += 64) yr[k] = expf(xr[k] - m) * inv;
+}
+
+int launch_softmax_rows_generic(const float* x, float* y, int64_t rows, int A, int64_t ld, hipStream_t stream)
+{
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipLaunchKernelGGL(softmax_rows_generic_kernel, grid, block, 0, stream, x, y, rows, A, ld);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+template <typename RI>
+int launch_ctc_generic(const CtcLatticeArgs<RI>& la, const CtcGradArgs<RI>& ga, int B, int max_T, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ctc_lattice_generic_kernel<RI>, dim3(B, 2), dim3(GEN_NT), 0, stream, la);
+    SCTC_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(ctc_grad_generic_kernel<RI>, dim3(max_T, B), dim3(256), 0, stream, ga);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
+template int launch_ctc_generic<float>(const CtcLatticeArgs<float>&, const CtcGradArgs<float>&, int, int, hipStream_t);
+template int launch_ctc_generic<double>(const CtcLatticeArgs<double>&, const CtcGradArgs<double>&, int, int, hipStream_t);
+
+}  // namespace sctc

@@ -87,7 +87,8 @@ int launch_softmax_rows(const float* x, float* y, int64_t rows, int A, int64_t l
                         hipStream_t stream)
 {
     if (rows <= 0) return SCTC_OK;
-    SCTC_CHECK_ARG(A >= 1 && A <= 256, "softmax_rows: alphabet %d not in [1,256]", A);
+    SCTC_CHECK_ARG(A >= 1, "softmax_rows: alphabet %d < 1", A);
+    if (A > 256) return launch_softmax_rows_generic(x, y, rows, A, ld, stream);
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if (A <= 64)
         hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, block, 0, stream, x, y, rows, A, ld);

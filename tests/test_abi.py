@@ -70,9 +70,11 @@ def test_argument_errors_need_no_gpu(sctc):
     assert sizes.workspace_bytes > 0
     big = sctc.BrnnConfig(20, 6, 4096, 3, 2, 10, 1, 20.0, 0.0, 1)   # 512 workgroups per pass: cannot be
     assert L.sctc_brnn_query(ctypes.byref(big), ctypes.byref(sizes)) == 0   # persistent -> per-step launches
-    bad = sctc.BrnnConfig(20, 300, 30, 3, 2, 10, 1, 20.0, 0.0, 1)
+    wide = sctc.BrnnConfig(20, 300, 30, 3, 2, 10, 1, 20.0, 0.0, 1)   # alphabets beyond 256 symbols: accepted since
+    assert L.sctc_brnn_query(ctypes.byref(wide), ctypes.byref(sizes)) == 0   # round 5 (ctc_generic.hip), like the reference
+    bad = sctc.BrnnConfig(20, 1, 30, 3, 2, 10, 1, 20.0, 0.0, 1)
     assert L.sctc_brnn_query(ctypes.byref(bad), ctypes.byref(sizes)) == -1
-    assert b"alphabet" in L.sctc_last_error()
+    assert b"dimensions" in L.sctc_last_error()
     with pytest.raises(ValueError):
         sctc.check(-1, "x")
     T = np.array([5], dtype=np.int32)
@@ -84,7 +86,15 @@ def test_argument_errors_need_no_gpu(sctc):
     assert L.sctc_ctc_workspace_bytes(ctypes.byref(bt)) == 0      # empty label sequence rejected
     U[0] = 2
     n = L.sctc_ctc_workspace_bytes(ctypes.byref(bt))
-    assert n >= 2 * 5 * 128 * 8                                   # two float64 lattices of 5 x 128
+    assert n >= 5 * 6 * 8                                         # fused path: ONE packed float64 half lattice per direction
+    os.environ["SCTC_CTC_FUSED"] = "0"
+    try:
+        assert L.sctc_ctc_workspace_bytes(ctypes.byref(bt)) >= 2 * 5 * 128 * 8   # two float64 lattices of 5 x 128
+    finally:
+        del os.environ["SCTC_CTC_FUSED"]
+    U[0] = 1500                                                   # 2U+1 > 2048: the generic kernels, no rejection
+    T[0] = 1600
+    assert L.sctc_ctc_workspace_bytes(ctypes.byref(bt)) >= 2 * 1600 * 3001 * 8
 
 
 def test_reference_surface_names(sctc):

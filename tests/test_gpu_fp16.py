@@ -62,6 +62,25 @@ def grad_errs(net, g, NL):
     return out
 
 
+def host_grads(net, NL):
+    out = {}
+    for i in range(NL + 1):
+        out["W%d" % (i + 1)] = net.grad[i][0].copy_to_host().astype(np.float64)
+        out["b%d" % (i + 1)] = net.grad[i][1].copy_to_host().astype(np.float64).reshape(-1)
+    out["Wf"] = net.grad[NL + 1][0].copy_to_host().astype(np.float64)
+    out["Wb"] = net.grad[NL + 2][0].copy_to_host().astype(np.float64)
+    return out
+
+
+def oracle_dict(g, NL):
+    out = {}
+    for i in range(NL + 1):
+        out["W%d" % (i + 1)] = g["W"][i]
+        out["b%d" % (i + 1)] = np.asarray(g["b"][i]).reshape(-1)
+    out["Wf"], out["Wb"] = g["Wf"], g["Wb"]
+    return out
+
+
 def test_gemm_h16_all_layouts(mods):
     """sctc_gemm_h16 in the four operand layouts, ragged sizes, float16 and bfloat16 operands,
     against the float64 product of the ROUNDED operands (the only error left is fp32 summation)"""
@@ -196,15 +215,42 @@ def test_fp16_cfg5_full_size(mods):
     assert all(v < tol(k, 6e-3) for k, v in e_m.items()), e_m
     assert all(v < tol(k, 1e-2) for k, v in e_x.items()), e_x
     del g_mx, g_ex
+    # ---- minibatch 8: the benchmarked workload (bench.py cfg5_fp16.minibatch_8), brnn_recurrent_mh_kernel with its
+    # 16-bit recurrent state over 8000 steps.  Gradients at size, three ways:
+    #  (i)   the whole minibatch against the SUM of the eight single-utterance device gradients (fp32 recurrence,
+    #        the path the B=1 comparison above pins to both oracles): isolates what the 16-bit state does;
+    #  (ii)  two utterances against Mixed(rec=True), the float64 restatement of exactly these roundings, and
+    #  (iii) against the exact float64 oracle -- both through linearity: minibatch(8) - minibatch(the other 6),
+    #        same recurrent kernel, is the two utterances' gradient.
     c8, _, s8 = net.costAndGradBatch(datas, labs)
-    assert not s8.any()
-    g8 = [net.grad[i][0].copy_to_host() for i in range(NL + 3)]
-    assert all(np.isfinite(g).all() for g in g8)
+    assert not s8.any() and net.recurrentPath()[0] == 1
+    g8 = host_grads(net, NL)
+    assert all(np.isfinite(g).all() for g in g8.values())
     sel = [2, 5]
+    rest = [i for i in range(B) if i not in sel]
+    c6, _, _ = net.costAndGradBatch([datas[i] for i in rest], [labs[i] for i in rest])
+    np.testing.assert_allclose(c6, c8[rest], rtol=1e-5)               # batch-composition invariance
+    g6 = host_grads(net, NL)
+    for n_, i in enumerate(range(B)):
+        net.costAndGradBatch([datas[i]], [labs[i]], accumulate=(n_ > 0))
+    g1x8 = host_grads(net, NL)
+    e_state = {k: rel(g8[k], g1x8[k]) for k in g8}
+    cm8, g_m2, _ = oracle_parallel(params, [datas[i] for i in sel], [labs[i] for i in sel], TL, mixed_rec=True)
+    cx, g_x2, _ = oracle_parallel(params, [datas[i] for i in sel], [labs[i] for i in sel], TL)
+    two = {k: g8[k] - g6[k] for k in g8}
+    e_m8 = {k: rel(two[k], v) for k, v in oracle_dict(g_m2, NL).items()}
+    e_x8 = {k: rel(two[k], v) for k, v in oracle_dict(g_x2, NL).items()}
+    print("fp16 cfg5 B=8 (16-bit recurrent state, T=8000) gradients: whole minibatch vs the sum of 8 single-utterance "
+          "steps (fp32 state)", {k: "%.1e" % v for k, v in e_state.items()},
+          "| two utterances by linearity vs Mixed(rec=True)", {k: "%.1e" % v for k, v in e_m8.items()},
+          "| vs exact", {k: "%.1e" % v for k, v in e_x8.items()})
+    # Stated bounds: the configuration's tolerance against the exact oracle (module docstring (ii): 5e-2, dW1 ten
+    # times that like everywhere else); against Mixed(rec=True) the same 5e-2 -- a rounded recurrence of 8000 steps
+    # cannot be tracked closer than the exact one (docstring (i)); the 16-bit state itself, (i) above, 3e-2.
+    assert all(v < tol(k, 5e-2) for k, v in e_x8.items()), e_x8
+    assert all(v < tol(k, 5e-2) for k, v in e_m8.items()), e_m8
+    assert all(v < tol(k, 3e-2) for k, v in e_state.items()), e_state
     cm1, _, _ = oracle_parallel(params, [datas[2]], [labs[2]], TL, want_grad=False, procs=1, mixed_rec=False)
-    cm8, _, _ = oracle_parallel(params, [datas[i] for i in sel], [labs[i] for i in sel], TL,
-                                want_grad=False, mixed_rec=True)
-    cx, _, _ = oracle_parallel(params, [datas[i] for i in sel], [labs[i] for i in sel], TL, want_grad=False)
     print("fp16 cfg5: B=1 cost %.3f mixed %.3f (rel %.1e) exact %.3f (rel %.1e); B=8 vs mixed %.1e vs exact %.1e"
           % (c1[0], cm1[0], abs(c1[0] - cm1[0]) / cm1[0], cx[0], abs(c1[0] - cx[0]) / cx[0],
              np.max(np.abs(c8[sel] - cm8) / cm8), np.max(np.abs(c8[sel] - cx) / cx)))

@@ -245,6 +245,39 @@ def test_cfg5_long_utterances(mods):
     assert all(np.isfinite(v).all() for v in g1.values())
 
 
+def test_cfg1_full_size(mods):
+    """BASELINE configs[0] at its real size (until round 5 only its H <= 64 golden twin ran):
+    one synthetic utterance T=200, 28 symbols, 512 units, 2 layers with the temporal layer first, inputDim 615,
+    minibatch 1 -- cost and every gradient tensor against the plain float64 oracle
+    (ctc_fast/debug-utils/checkgrads.py:20-40 at this size)."""
+    brnnet, obrnn, torch = mods
+    D, A, H, NL, TL, T, U = 615, 28, 512, 2, 1, 200, 20
+    rs = np.random.RandomState(1)
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    data = rs.randn(D, T).astype(np.float32)
+    labels = rs.randint(1, A, size=U).astype(np.int32)
+    net = make_net(brnnet, (D, A, H, NL, TL, T), params)
+    cost, _, skip = net.costAndGrad(data, labels)
+    assert not skip
+    got = tensors(net, NL)
+    with np.errstate(all="ignore"):
+        c_ref, g_ref, s_ref, probs_ref = obrnn.cost_and_grad(params, data.astype(np.float64), labels, TL, 20.0)
+    assert not s_ref
+    assert cost == pytest.approx(c_ref, rel=1e-4)
+    want = oracle_tensors(g_ref, NL)
+    worst = {k: rel(got[k], want[k]) for k in want}
+    print("cfg1 full size: cost %.6f oracle %.6f rel err %.2e; gradient rel-norm errors:" % (cost, c_ref, abs(cost - c_ref) / c_ref),
+          {k: "%.1e" % v for k, v in worst.items()})
+    assert within_tol(worst), worst
+    net.costAndGrad(data, labels)                         # bit-reproducible
+    again = tensors(net, NL)
+    for k in got:
+        np.testing.assert_array_equal(got[k], again[k])
+    netf = make_net(brnnet, (D, A, H, NL, TL, T), params, train=False)
+    p = netf.costAndGrad(data)
+    assert p.shape == (A, T) and np.abs(p - probs_ref).max() < 1e-5
+
+
 @pytest.mark.parametrize("gemm", ["f32", "bf16x3"])
 def test_cfg2_timit_shape_full_size(mods, gemm):
     """BASELINE configs[1] at its real size: T=300, A=62, 3x1024, temporalLayer 2, inputDim 943

@@ -165,6 +165,33 @@ def test_bench_two_ranks(backend):
     assert same == (backend == "gloo")
 
 
+def test_bench_gpus2_without_a_launcher():
+    """`python bench.py --gpus 2 ...` as the driver's N = 1 line is written -- no torch.distributed.run in the
+    command, no RANK / WORLD_SIZE in the environment: the script starts the launcher itself (VERDICT r04 missing #4:
+    the first SCALE run must not die on the WORLD_SIZE assert).  gloo: both ranks on the one GPU of the box."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SCTC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "6", "--steps", "2", "--warmup", "1",
+           "--no-side", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                   # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["frames_per_step"] == 2 * 6 * 1000 and out["cost_check"]["rel_err"] < 1e-4
+    assert "without a launcher" in res.stderr
+    # a failing rank's exit status comes back through the self-launch
+    bad = subprocess.run(cmd[:2] + ["--gpus", "2", "--batch", "0", "--steps", "1", "--warmup", "0", "--no-side",
+                                    "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0
+
+
 def test_bench_four_ranks_gloo_on_one_gpu():
     """the driver's N = 4 launch line rehearsed on the one GPU of the box (gloo, all four ranks under the
     device lease): rank -> bus-id exchange over four ranks, four shards, MAX-over-ranks timing, one line"""

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""prints the fields of a bench.py JSON line that a session looks at first"""
+import json
+import sys
+
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("value %.0f %s  ms %.3f  frac %.4f  traffic %s" % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("traffic")))
+print("phases", {k: round(v, 3) for k, v in d.get("phase_ms", {}).items()})
+rc = d.get("roofline_ctc", {})
+print("ctc", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in rc.items() if k in ("achieved", "frac", "ms", "traffic", "traffic_ratio", "algorithmic_bytes")})
+if "saturating_batch" in rc:
+    print("ctc saturating", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in rc["saturating_batch"].items() if k != "note"})
+if "hbm_resident" in d:
+    print("hbm_resident %.0f" % d["hbm_resident"]["value"])
+rr = d.get("roofline_recurrent", {})
+if "by_minibatch" in rr:
+    print("rec by minibatch", {k: (round(v["us_per_time_step"], 2), round(v["frac_of_f32_mfma_peak"], 3)) for k, v in rr["by_minibatch"].items()})
+c5 = d.get("cfg5_fp16")
+if c5:
+    for k in ("minibatch_8", "minibatch_1"):
+        print(k, round(c5[k]["value"]), round(c5[k]["ms_per_step"], 2), {a: round(b, 2) for a, b in c5[k]["phase_ms"].items()})
+if "cpu_baseline" in d:
+    print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"])
