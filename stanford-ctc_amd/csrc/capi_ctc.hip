@@ -185,6 +185,10 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
         fa.store = d_store;
         fa.cost = cost;
         fa.skip = skip;
+        {
+            const char* dz = getenv("SCTC_CTC_DIAG");
+            fa.diag = dz ? atoi(dz) : 0;
+        }
         SCTC_TRY(launch_ctc_fused<R>(fa, plan.B, plan.K, plan.store_bytes, stream));
         if (!keep) SCTC_HIP_TRY(hipStreamSynchronize(stream));
         return SCTC_OK;

@@ -84,8 +84,8 @@ struct __attribute__((aligned(sizeof(ST) * K))) RowBlockA {
 
 }  // namespace
 
-template <typename RI, typename ST, int K, int NA>
-__global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
+template <typename RI, typename ST, int K, int NA, bool HELP>
+__global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
 {
     using R = double;
     static_assert(K == 2 || K == 4, "one wave per direction: 2 or 4 states per lane");
@@ -95,21 +95,41 @@ __global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
     // frame, so that the frames themselves are ONE basic block without a store or a branch: whatever
     // does not feed the recursion is scheduled into the gaps of its dependency chain.
     constexpr int PF = 8;
-    constexpr int NI = NA == 1 ? 8 : 4;     // list entries of a label kept in registers
+    constexpr int NI = NA == 1 ? 8 : 4;     // list entries of a label summed unconditionally
+    constexpr int NI2 = NA == 1 ? 16 : NI;  // list entries kept in registers (those beyond NI: summed when some list is that long)
     constexpr int NPOS = 64 * KH;           // label positions of one direction; slot NPOS holds 0.0
     constexpr int LSTR = NPOS + 2;
-    constexpr int RSTR = 66;                // row stride of the reduction scratch (bank spread)
+    constexpr int RSTR = (HELP && K == 2) ? 64 : 66;   // row stride of the reduction scratch (bank spread where it fits)
     using BlkU = RowBlockU<ST, K>;
     using BlkA = RowBlockA<ST, K>;
 
-    __shared__ __attribute__((aligned(16))) double lab_s[2][PF][LSTR];   // alpha*beta of the label states, per frame of a block
-    __shared__ __attribute__((aligned(16))) double red_s[2][2 * PF][RSTR];
+    // HELP: four more waves per utterance, two per direction, form the gradient (phase 1) from the rows the
+    // recursion waves hand over through an LDS ring of 2 x HB frames -- helper `par` of a direction takes the
+    // hand-overs of parity par, from ring half par.  A phase-1 frame then costs the recursion wave LESS than a
+    // phase-0 frame (the row goes to LDS instead of HBM: 0.21 against 0.23-0.29 us, round 5), and the products,
+    // sums and gradient rows issue on other SIMDs.  Without helpers they issue in the recursion wave itself: a
+    // phase-1 frame is then issue-bound at 2-3x a phase-0 frame (0.45 ms against the three-kernel path's 0.31 at
+    // cfg-3 minibatch 32); one helper per direction is not enough either (0.33-0.47 us per frame: its hand-over is a
+    // chain of LDS round trips).  The saturating batch runs without helpers (more utterances resident per CU).
+    constexpr int HB = 4;                   // frames per hand-over
+    constexpr int FS = HELP ? HB : PF;      // frames per finish (LDS slots of label products, transposed sums)
+    constexpr int NH = HELP ? 2 : 1;        // helpers per direction
+    __shared__ __attribute__((aligned(16))) double lab_s[2][NH][FS][LSTR];   // alpha*beta of the label states, per frame
+    // the transposed sums of a finish: their own scratch without helpers; with helpers the ring half the helper has
+    // just read into registers (released once the sums are read back)
+    __shared__ __attribute__((aligned(16))) double red_s[HELP ? 1 : 2][HELP ? 1 : 2 * FS][HELP ? 2 : RSTR];
+    __shared__ __attribute__((aligned(16))) double ring_s[HELP ? 2 : 1][2][HB][HELP ? 64 * K : 2];
+    static_assert(!HELP || 2 * HB * RSTR <= HB * 64 * K, "the sums of a hand-over fit its ring half");
+    __shared__ int32_t prod_s[2], cons_s[2][2];   // hand-overs published per direction / consumed per helper
     __shared__ int32_t ord_pos[2][NPOS];
     __shared__ int32_t sh_skip[2];
-    __shared__ double sh_cost;
+    __shared__ double sh_cost;     // written by wave 0 (dir 0), read after a barrier
 
     const int b = blockIdx.x;
-    const int dir = threadIdx.x >> 6;   // 0: alpha, 1: beta (== alpha of the reversed problem)
+    const int wave = threadIdx.x >> 6;
+    const int dir = wave & 1;           // 0: alpha, 1: beta (== alpha of the reversed problem)
+    const bool helper = wave >= 2;      // HELP only: waves 2..5
+    const int par = helper ? (wave - 2) >> 1 : 0;
     const int lane = threadIdx.x & 63, gl = lane;
     const CtcUtt u = p.utts[b];
     const int T = u.T, U = u.U, L = 2 * U + 1;
@@ -151,7 +171,7 @@ __global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
     const bool orow_lane = K * gl < L;
 
     // ---- gradient side: lane k (+64q) owns label k's list of label positions, in MY direction's order
-    int lidx[NA][NI];
+    int lidx[NA][NI2];
     int llen[NA], lj0[NA];
     int maxlen = 0;
     {
@@ -161,9 +181,14 @@ __global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
             const int i = byl[j] >> 1;                    // by_label holds states 2i+1
             ord_pos[dir][j] = dir ? U - 1 - i : i;
         }
-        if (lane < PF) {
-            lab_s[dir][lane][NPOS] = 0.0;
-            lab_s[dir][lane][NPOS + 1] = 0.0;
+        if (lane < FS) {
+            lab_s[dir][par][lane][NPOS] = 0.0;
+            lab_s[dir][par][lane][NPOS + 1] = 0.0;
+        }
+        if (lane == 0 && !helper) {
+            prod_s[dir] = 0;
+            cons_s[dir][0] = 0;
+            cons_s[dir][1] = 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -176,11 +201,20 @@ __global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
             llen[q] = j1 - j0;
             maxlen = max(maxlen, llen[q]);
 #pragma unroll
-            for (int n = 0; n < NI; ++n) lidx[q][n] = n < llen[q] ? ord_pos[dir][j0 + n] : NPOS;
+            for (int n = 0; n < NI2; ++n) lidx[q][n] = n < llen[q] ? ord_pos[dir][j0 + n] : NPOS;
         }
         maxlen = wave_max(maxlen);
     }
 
+    // Accesses of ONE wave to LDS execute in program order: between a wave's own LDS writes and its reads of what
+    // other lanes wrote (and between a hand-over's rows and its flag) only the COMPILER has to keep the order.  (A
+    // workgroup-scope fence would also wait for the wave's global loads and stores: the helper would stall on its
+    // gradient rows once per hand-over.)
+    auto lds_order = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    };
     auto load_row = [&](int64_t row, RI (&dst)[NA]) {
         const RI* yr = probs + row * ld;
 #pragma unroll
@@ -211,6 +245,24 @@ __global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
             if ((k >> 6) == q) out = o;
         }
         return (R)out;
+    };
+    auto gather_d = [&](const R (&y)[NA], int k) -> R {
+        R out = lane_gather(y[0], k & 63);
+#pragma unroll
+        for (int q = 1; q < NA; ++q) {
+            R o = lane_gather(y[q], k & 63);
+            if ((k >> 6) == q) out = o;
+        }
+        return out;
+    };
+    auto bcast_d = [&](const R (&y)[NA], int k) -> R {
+        R out = lane_bcast(y[0], k & 63);
+#pragma unroll
+        for (int q = 1; q < NA; ++q) {
+            R o = lane_bcast(y[q], k & 63);
+            if ((k >> 6) == q) out = o;
+        }
+        return out;
     };
     // the other direction's row of MY frame tau: its own time index is T-1-tau, its state order mine mirrored
     auto load_other = [&](int tau, BlkU& dst) {
@@ -317,12 +369,12 @@ __global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
     };
     // phase 1, inside the frame: alpha*beta of my states against the other direction's stored row;
     // label products to the frame's LDS slot, the lane's share of absum[t] (zl) and of the blank sum (eb)
-    auto products = [&](int slot, const BlkU& ob, R rb, const R (&rl)[KH], R& zl, R& eb) {
+    auto products = [&](int slot, const R (&av)[K], const BlkU& ob, R rb, const R (&rl)[KH], R& zl, R& eb) {
         R ab[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const R o = Store<ST>::dec(ob.v[K - 1 - j]);
-            ab[j] = a[j] * (inrow[j] ? o : (R)0);                       // :119
+            ab[j] = av[j] * (inrow[j] ? o : (R)0);                      // :119
         }
         R z = (R)0, e = (R)0;
 #pragma unroll
@@ -334,65 +386,110 @@ __global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
         zl = z;
         eb = e;
         if constexpr (KH == 2) {
-            *reinterpret_cast<double2*>(&lab_s[dir][slot][2 * gl]) = make_double2(ab[1], ab[3]);
+            *reinterpret_cast<double2*>(&lab_s[dir][par][slot][2 * gl]) = make_double2(ab[1], ab[3]);
         } else {
-            lab_s[dir][slot][gl] = ab[1];
+            lab_s[dir][par][slot][gl] = ab[1];
         }
     };
     // phase 1, behind a block's frames: absum and the blank sum of its PF frames (2 PF sums over the wave,
     // transposed through LDS: lane -> (sum, quarter) instead of 2 PF wave reductions), the per-label sums
     // (:120-131) from the frames' LDS slots, the gradient rows (:138-145)
-    auto finish_block = [&](int tb, int t_end, const RI (&yc)[PF][NA], int rows, const R (&zl)[PF], const R (&eb)[PF]) {
-        static_assert(2 * PF * 4 == 64, "one lane per (sum, quarter)");
+    auto finish_block = [&](auto nf_tag, double* red, auto&& release, int tb, int t_end,
+                            const RI (&yc)[decltype(nf_tag)::value][NA], int rows,
+                            const R (&zl)[decltype(nf_tag)::value], const R (&eb)[decltype(nf_tag)::value]) {
+        constexpr int NF = decltype(nf_tag)::value;     // frames finished together: PF, or HB with helper waves
+        constexpr int PARTS = 64 / (2 * NF);            // lanes per sum
+        constexpr int PER = 64 / PARTS;                 // values per lane
+        static_assert(NF <= FS && (NF == 8 || NF == 4), "one lane per (sum, part)");
+        // the label products of the frames' slots: where they fit into registers they are fetched first and return
+        // while the sums cross LDS
+        constexpr bool EARLY = NF * NA * NI <= 32;
+        R lv[EARLY ? NF : 1][EARLY ? NA : 1][NI];
+        if constexpr (EARLY) {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            red_s[dir][i][lane] = zl[i];
-            red_s[dir][PF + i][lane] = eb[i];
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int q = 0; q < NA; ++q)
+#pragma unroll
+                    for (int n = 0; n < NI; ++n) lv[i][q][n] = lab_s[dir][par][i][lidx[q][n]];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            red[i * RSTR + lane] = zl[i];
+            red[(NF + i) * RSTR + lane] = eb[i];
+        }
+        lds_order();
         R tot;
         {
-            const double2* src = reinterpret_cast<const double2*>(&red_s[dir][lane >> 2][(lane & 3) * 16]);
-            double2 v[8];
+            const double2* src = reinterpret_cast<const double2*>(red + (lane / PARTS) * RSTR + (lane % PARTS) * PER);
+            double2 v[PER / 2];
 #pragma unroll
-            for (int n = 0; n < 8; ++n) v[n] = src[n];
-            R s[8];
+            for (int n = 0; n < PER / 2; ++n) v[n] = src[n];
+            lds_order();
+            release();                                  // (helpers: the ring half may be written again)
+            R s[PER / 2];
 #pragma unroll
-            for (int n = 0; n < 8; ++n) s[n] = v[n].x + v[n].y;
-            tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+            for (int n = 0; n < PER / 2; ++n) s[n] = v[n].x + v[n].y;
+#pragma unroll
+            for (int w = 1; w < PER / 2; w *= 2)
+#pragma unroll
+                for (int n = 0; n + w < PER / 2; n += 2 * w) s[n] += s[n + w];
+            tot = s[0];
             tot += quad_xor(tot, std::integral_constant<int, 0xB1>());   // quad_perm [1,0,3,2]
             tot += quad_xor(tot, std::integral_constant<int, 0x4E>());   // quad_perm [2,3,0,1]
+            if constexpr (PARTS == 8) tot += __shfl_xor(tot, 4, 64);
         }
-        R g[PF][NA];
+        R g[NF][NA];
 #pragma unroll
-        for (int i = 0; i < PF; ++i)
+        for (int i = 0; i < NF; ++i)
 #pragma unroll
             for (int q = 0; q < NA; ++q) {
                 R v[NI];
 #pragma unroll
-                for (int n = 0; n < NI; ++n) v[n] = lab_s[dir][i][lidx[q][n]];
+                for (int n = 0; n < NI; ++n) {
+                    if constexpr (EARLY) v[n] = lv[i][q][n];
+                    else v[n] = lab_s[dir][par][i][lidx[q][n]];
+                }
 #pragma unroll
                 for (int w = 1; w < NI; w *= 2)
 #pragma unroll
                     for (int n = 0; n + w < NI; n += 2 * w) v[n] += v[n + w];
                 g[i][q] = v[0];
             }
-        if (maxlen > NI) {   // a label with more than NI positions (uniform): the rest of every list
+        if (maxlen > NI) {   // a label with more than NI positions (uniform over the wave)
+            if constexpr (NI2 > NI) {
+                // positions NI .. NI2-1 from registers, four at a time
 #pragma unroll
-            for (int q = 0; q < NA; ++q)
-                for (int n = NI; n < maxlen; ++n) {
-                    const int pos = n < llen[q] ? ord_pos[dir][lj0[q] + n] : NPOS;
+                for (int n0 = NI; n0 < NI2; n0 += 4) {
+                    if (maxlen > n0) {
 #pragma unroll
-                    for (int i = 0; i < PF; ++i) g[i][q] += lab_s[dir][i][pos];
+                        for (int q = 0; q < NA; ++q) {
+                            R w4[NF][4];
+#pragma unroll
+                            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                                for (int n = 0; n < 4; ++n) w4[i][n] = lab_s[dir][par][i][lidx[q][n0 + n]];
+#pragma unroll
+                            for (int i = 0; i < NF; ++i) g[i][q] += (w4[i][0] + w4[i][1]) + (w4[i][2] + w4[i][3]);
+                        }
+                    }
                 }
-        }
-        RI out[PF][NA];
+            }
+            if (maxlen > NI2) {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const R Z = lane_bcast(tot, 4 * i);                          // absum[t], :133-136
-            const R gb = lane_bcast(tot, 4 * (PF + i));
+                for (int q = 0; q < NA; ++q)
+                    for (int n = NI2; n < maxlen; ++n) {
+                        const int pos = n < llen[q] ? ord_pos[dir][lj0[q] + n] : NPOS;
+#pragma unroll
+                        for (int i = 0; i < NF; ++i) g[i][q] += lab_s[dir][par][i][pos];
+                    }
+            }
+        }
+        RI out[NF][NA];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const R Z = lane_bcast(tot, PARTS * i);                      // absum[t], :133-136
+            const R gb = lane_bcast(tot, PARTS * (NF + i));
 #pragma unroll
             for (int q = 0; q < NA; ++q) {
                 const int k = lane + 64 * q;
@@ -407,15 +504,14 @@ __global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
             const int k = lane + 64 * q;
             if (k < A) {
 #pragma unroll
-                for (int i = 0; i < PF; ++i)
+                for (int i = 0; i < NF; ++i)
                     if (tb + i < t_end)
                         grad[((int64_t)__builtin_amdgcn_readlane(rows, i) + u.row0) * ld + k] = out[i][q];
             }
         }
         // the next block's products overwrite the slots: LDS executes a wave's accesses in order, the
         // compiler must keep them in order too
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        lds_order();
     };
 
     // ---- frames [t_begin, t_end) of my direction; PH 0: store the rows, PH 1: form the gradient
@@ -458,7 +554,7 @@ __global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
                     R rl[KH];
 #pragma unroll
                     for (int jj = 0; jj < KH; ++jj) rl[jj] = recip_or_zero(ylv[i][jj]);
-                    products(i, ocur[i], recip_or_zero(ybv[i]), rl, zl[i], eb[i]);
+                    products(i, a, ocur[i], recip_or_zero(ybv[i]), rl, zl[i], eb[i]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < K; ++j) enc[i].v[j] = Store<ST>::enc(a[j]);
@@ -484,7 +580,8 @@ __global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
                 }
             }
             if constexpr (PH) {
-                finish_block(tb, t_end, ycur, rb_cur, zl, eb);
+                if constexpr (!HELP)
+                    finish_block(std::integral_constant<int, PF>(), &red_s[dir][0][0], [] {}, tb, t_end, ycur, rb_cur, zl, eb);
             } else {
                 if (store_lane) {
 #pragma unroll
@@ -505,8 +602,168 @@ __global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
         }
     };
 
+    // ---- HELP, phase 1, recursion wave: the frames [t_begin, t_end) like phase 0, the rows handed to the helper
+    // through ring_s -- HB frames per hand-over, two hand-overs in flight
+    constexpr int ABORT = 0x7fffffff;
+    auto publish = [&](int v) {
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(&prod_s[dir], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+    };
+    // every spin is bounded (about half a second): both waves of a hand-over belong to one workgroup and are
+    // resident together, so a wait is a few microseconds -- but a wait that never ends would take the device with
+    // it.  A wait that ran out makes the utterance's cost NaN (the host sees it).
+    int timed_out = 0;
+    auto wait_for = [&](int32_t* word, int need) {
+        if (need <= 0) return;
+        int spins = 0;
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 23)) {
+                timed_out = 1;
+                break;
+            }
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto produce = [&](int t_begin, int t_end) {
+        if (t_begin >= t_end) return;
+        if (skip) {
+            publish(ABORT);
+            return;
+        }
+        const int nblk = (t_end - t_begin + PF - 1) / PF;
+        RI ycur[PF][NA];
+        int rb_cur = block_rows(t_begin);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) load_row((int64_t)__builtin_amdgcn_readlane(rb_cur, i) + u.row0, ycur[i]);
+        int rb_nxt = block_rows(t_begin + PF);
+        for (int blk = 0; blk < nblk && !skip; ++blk) {
+            const int tb = t_begin + blk * PF;
+            RI ynxt[PF][NA];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) load_row((int64_t)__builtin_amdgcn_readlane(rb_nxt, i) + u.row0, ynxt[i]);
+            const int rb_next2 = block_rows(tb + 2 * PF);
+            R ybv[PF], ylv[PF][KH];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                ybv[i] = bcast(ycur[i], blank);
+#pragma unroll
+                for (int jj = 0; jj < KH; ++jj) {
+                    const R g = gather(ycur[i], lab[jj]);
+                    ylv[i][jj] = valid_lab[jj] ? g : (R)0;
+                }
+            }
+            const bool fast = (tb + PF - 1 < t_end) && (L <= 2 * (T - (tb + PF - 1)));
+#pragma unroll
+            for (int hb = 0; hb < PF / HB; ++hb) {
+                const int h = blk * (PF / HB) + hb;
+                if (!(p.diag & 8)) wait_for(&cons_s[dir][h & 1], h >> 1);   // hand-over h - 2 (same ring half) has been consumed
+                double2* slot = reinterpret_cast<double2*>(&ring_s[dir][h & 1][0][0]);
+                if (fast) {
+#pragma unroll
+                    for (int i = 0; i < HB; ++i) {
+                        step(std::true_type(), tb + hb * HB + i, ybv[hb * HB + i], ylv[hb * HB + i]);
+#pragma unroll
+                        for (int j = 0; j < K; j += 2) slot[(i * 64 * K + K * lane + j) / 2] = make_double2(a[j], a[j + 1]);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < HB; ++i) {
+                        if (tb + hb * HB + i < t_end)
+                            step(std::false_type(), tb + hb * HB + i, ybv[hb * HB + i], ylv[hb * HB + i]);
+#pragma unroll
+                        for (int j = 0; j < K; j += 2) slot[(i * 64 * K + K * lane + j) / 2] = make_double2(a[j], a[j + 1]);
+                    }
+                }
+                publish(h + 1);
+            }
+            if (first_bad != NO_BAD) skip = 1;
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+#pragma unroll
+                for (int q = 0; q < NA; ++q) ycur[i][q] = ynxt[i][q];
+            rb_cur = rb_nxt;
+            rb_nxt = rb_next2;
+        }
+        if (skip) publish(ABORT);   // the helper runs through what is left (its rows are taken back below)
+    };
+    // ---- HELP, phase 1, helper wave `par`: the hand-overs h = par, par + 2, ... -- per hand-over the products against
+    // the other direction's stored rows, then the HB gradient rows
+    auto consume = [&](int t_begin, int t_end) {
+        if (t_begin >= t_end) return;
+        const int nh = (t_end - t_begin + PF - 1) / PF * (PF / HB);
+        RI ycur[HB][NA];
+        BlkU ocur[HB];
+        int rb_cur = block_rows(t_begin + par * HB);
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            load_row((int64_t)__builtin_amdgcn_readlane(rb_cur, i) + u.row0, ycur[i]);
+            load_other(t_begin + par * HB + i, ocur[i]);
+        }
+        int rb_nxt = block_rows(t_begin + (par + 2) * HB);
+        double* half = &ring_s[dir][par][0][0];
+        for (int h = par; h < nh; h += 2) {
+            const int tb = t_begin + h * HB;
+            RI ynxt[HB][NA];
+            BlkU onxt[HB];
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                load_row((int64_t)__builtin_amdgcn_readlane(rb_nxt, i) + u.row0, ynxt[i]);
+                load_other(tb + 2 * HB + i, onxt[i]);
+            }
+            const int rb_next2 = block_rows(tb + 4 * HB);
+            // 1/y for every symbol of a frame at once (lane k <- 1/y[k]), then gathered per state like y itself
+            R rbv[HB], rlv[HB][KH];
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                R ry[NA];
+#pragma unroll
+                for (int q = 0; q < NA; ++q) ry[q] = recip_or_zero((R)ycur[i][q]);
+                rbv[i] = bcast_d(ry, blank);
+#pragma unroll
+                for (int jj = 0; jj < KH; ++jj) {
+                    const R g = gather_d(ry, lab[jj]);
+                    rlv[i][jj] = valid_lab[jj] ? g : (R)0;
+                }
+            }
+            wait_for(&prod_s[dir], h + 1);
+            R zl[HB], eb[HB];
+            const double2* slot = reinterpret_cast<const double2*>(half);
+            R av[HB][K];
+#pragma unroll
+            for (int i = 0; i < HB; ++i)
+#pragma unroll
+                for (int j = 0; j < K; j += 2) {
+                    const double2 v = slot[(i * 64 * K + K * lane + j) / 2];
+                    av[i][j] = v.x;
+                    av[i][j + 1] = v.y;
+                }
+            lds_order();     // the rows are in registers before the half is reused for the sums
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                if (!(p.diag & 4)) products(i, av[i], ocur[i], rbv[i], rlv[i], zl[i], eb[i]);
+                else { zl[i] = av[i][0]; eb[i] = av[i][1]; }
+            }
+            auto release = [&]() {
+                __hip_atomic_store(&cons_s[dir][par], (h >> 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");
+            };
+            if (!(p.diag & 2)) finish_block(std::integral_constant<int, HB>(), half, release, tb, t_end, ycur, rb_cur, zl, eb);
+            else release();
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+#pragma unroll
+                for (int q = 0; q < NA; ++q) ycur[i][q] = ynxt[i][q];
+                ocur[i] = onxt[i];
+            }
+            rb_cur = rb_nxt;
+            rb_nxt = rb_next2;
+        }
+    };
+
     // ---- tau = 0 (ctc_fast.pyx:42-47 / :79-84); it belongs to phase 1 only when T == 1 (alpha stores nothing)
-    {
+    if (!helper) {
         RI y0[NA];
         const int t = dir ? T - 1 : 0;
         const int64_t row0 = (int64_t)(p.rowbase ? p.rowbase[t] : t) + u.row0;
@@ -530,37 +787,45 @@ __global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
             for (int j = 0; j < K; ++j) blk.v[j] = Store<ST>::enc(a[j]);
             *reinterpret_cast<BlkA*>(mine + K * gl) = blk;
         }
+        run(std::integral_constant<int, 0>(), 1, Tst);
     }
-    run(std::integral_constant<int, 0>(), 1, Tst);
     __syncthreads();   // phase 0 rows of both directions are in L2 (vmcnt(0) + barrier; same CU)
-    if (Tst == 0 && !skip) {
-        // T == 1, alpha: the one frame's gradient against beta's stored row 0
-        RI yc[PF][NA];
+    if (!helper && Tst == 0 && !skip) {
+        // T == 1, alpha: the one frame's gradient against beta's stored row 0 (the recursion wave itself)
+        RI yc[FS][NA];
         const int rows = p.rowbase ? p.rowbase[0] : 0;
 #pragma unroll
-        for (int i = 0; i < PF; ++i) load_row((int64_t)rows + u.row0, yc[i]);
+        for (int i = 0; i < FS; ++i) load_row((int64_t)rows + u.row0, yc[i]);
         BlkU ob;
         load_other(0, ob);
-        R rl[KH], zl[PF], eb[PF];
+        R rl[KH], zl[FS], eb[FS];
 #pragma unroll
-        for (int i = 0; i < PF; ++i) { zl[i] = (R)0; eb[i] = (R)0; }
+        for (int i = 0; i < FS; ++i) { zl[i] = (R)0; eb[i] = (R)0; }
 #pragma unroll
         for (int jj = 0; jj < KH; ++jj) {
             const R g = gather(yc[0], lab[jj]);
             rl[jj] = recip_or_zero(valid_lab[jj] ? g : (R)0);
         }
-        products(0, ob, recip_or_zero(bcast(yc[0], blank)), rl, zl[0], eb[0]);
-        finish_block(0, 1, yc, rows, zl, eb);
+        products(0, a, ob, recip_or_zero(bcast(yc[0], blank)), rl, zl[0], eb[0]);
+        finish_block(std::integral_constant<int, FS>(), HELP ? &ring_s[0][0][0][0] : &red_s[0][0][0], [] {}, 0, 1, yc, rows, zl, eb);
     }
-    run(std::integral_constant<int, 1>(), Tst > 0 ? Tst : 1, T);
+    const int t1_end = (p.diag & 1) ? 0 : T;
+    if constexpr (HELP) {
+        if (helper) consume(Tst > 0 ? Tst : 1, t1_end);
+        else produce(Tst > 0 ? Tst : 1, t1_end);
+    } else {
+        run(std::integral_constant<int, 1>(), Tst > 0 ? Tst : 1, t1_end);
+    }
 
-    if (dir == 0 && lane == 0) {
+    if (wave == 0 && lane == 0) {
         // -llForward (ctc_fast.pyx:149,152); math.log(0.0) for the empty band
         double cost = log(ll_m) + (double)ll_e * 0.693147180559945309417232121458;
         if (empty_band && !skip) cost = INFINITY;
         sh_cost = cost;
     }
-    if (lane == 0) sh_skip[dir] = skip;
+    if (lane == 0 && !helper) sh_skip[dir] = skip;
+    __syncthreads();
+    if (timed_out && lane == 0) sh_cost = NAN;     // (benign race: every writer writes NaN)
     __syncthreads();
     const int any_skip = sh_skip[0] | sh_skip[1];
     if (threadIdx.x == 0) {
@@ -570,7 +835,7 @@ __global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
     if (any_skip) {
         // the reference returns its zero-initialised grad (ctc_fast.pyx:31-32,149): rows written before
         // the failing frame was reached are taken back
-        for (int t = dir; t < T; t += 2) {
+        for (int t = wave; t < T; t += (HELP ? 6 : 2)) {
             RI* gr = grad + ((int64_t)(p.rowbase ? p.rowbase[t] : t) + u.row0) * ld;
             for (int k = lane; k < A; k += 64) gr[k] = (RI)0;
         }
@@ -579,15 +844,30 @@ __global__ __launch_bounds__(128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
 
 // ---------------------------------------------------------------- launcher
 
+template <typename RI, typename ST, int K, bool HELP>
+static int launch_fused_kh(const CtcFusedArgs<RI>& a, int B, int NA, hipStream_t stream)
+{
+    dim3 grid(B), block(HELP ? 384 : 128);
+    if (NA == 1) hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, 1, HELP>), grid, block, 0, stream, a);
+    else if (NA == 2) hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, 2, HELP>), grid, block, 0, stream, a);
+    else if constexpr (!HELP) hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, 4, false>), grid, block, 0, stream, a);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
 template <typename RI, typename ST, int K>
 static int launch_fused_k(const CtcFusedArgs<RI>& a, int B, int NA, hipStream_t stream)
 {
-    dim3 grid(B), block(128);
-    if (NA == 1) hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, 1>), grid, block, 0, stream, a);
-    else if (NA == 2) hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, 2>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, 4>), grid, block, 0, stream, a);
-    SCTC_HIP_TRY(hipGetLastError());
-    return SCTC_OK;
+    // Helper waves (six waves per utterance) while the batch leaves SIMDs idle; beyond SCTC_CTC_HELPER_MAX_B
+    // utterances (default 512: two workgroups per CU) the two-wave form keeps more utterances resident.  Alphabets
+    // of more than 128 symbols (four probability registers per frame) always take the two-wave form: the helper's
+    // register budget is 256.  SCTC_CTC_HELPER=0 / 1 forces one form (A/B, tests).
+    const char* hz = getenv("SCTC_CTC_HELPER");
+    const char* mz = getenv("SCTC_CTC_HELPER_MAX_B");
+    const int max_b = mz ? atoi(mz) : 512;
+    const bool help = NA <= 2 && (hz ? atoi(hz) != 0 : B <= max_b);
+    if (help) return launch_fused_kh<RI, ST, K, true>(a, B, NA, stream);
+    return launch_fused_kh<RI, ST, K, false>(a, B, NA, stream);
 }
 
 template <typename RI>

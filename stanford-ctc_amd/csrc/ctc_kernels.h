@@ -72,6 +72,8 @@ struct CtcFusedArgs {
     void* store;
     double* cost;    // [B]
     int32_t* skip;   // [B]
+    int32_t diag;    // SCTC_CTC_DIAG, timing experiments only (results are wrong): 1 no phase 1, 2 helper without
+                     // finish, 4 helper without products, 8 recursion waves do not wait for the helper
 };
 template <typename RI>
 int launch_ctc_fused(const CtcFusedArgs<RI>& a, int B, int K, int store_bytes, hipStream_t stream);

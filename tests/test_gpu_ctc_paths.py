@@ -1,6 +1,7 @@
 """GPU parity of the three CTC code paths behind `ctc_fast.ctc_loss` / `ctc_loss_batch` (round 5):
 
-  fused     ctc_fused.hip      both recursions + the gradient in one kernel, rows of <= 256 states (default there)
+  fused     ctc_fused.hip      both recursions + the gradient in one kernel, rows of <= 256 states (default there);
+                               "fused2w" = the same without helper waves (SCTC_CTC_HELPER=0)
   lattice   ctc_kernels.hip    ctc_lattice + ctc_grad, rows of <= 2048 states (SCTC_CTC_FUSED=0 forces it)
   generic   ctc_generic.hip    any label length, any alphabet (SCTC_CTC_GENERIC=1 forces it)
 
@@ -30,14 +31,15 @@ def mods():
 
 class path:
     """context manager: force one CTC path through the environment switches the plan reads per call"""
-    ENV = {"fused": {}, "fused64": {"SCTC_CTC_STORE": "64"}, "lattice": {"SCTC_CTC_FUSED": "0"},
-           "generic": {"SCTC_CTC_GENERIC": "1"}}
+    ENV = {"fused": {}, "fused64": {"SCTC_CTC_STORE": "64"}, "fused2w": {"SCTC_CTC_HELPER": "0"},
+           "lattice": {"SCTC_CTC_FUSED": "0"}, "generic": {"SCTC_CTC_GENERIC": "1"}}
+    VARS = ("SCTC_CTC_STORE", "SCTC_CTC_FUSED", "SCTC_CTC_GENERIC", "SCTC_CTC_HELPER")
 
     def __init__(self, name):
         self.env = self.ENV[name]
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in ("SCTC_CTC_STORE", "SCTC_CTC_FUSED", "SCTC_CTC_GENERIC")}
+        self.old = {k: os.environ.get(k) for k in self.VARS}
         for k in self.old:
             os.environ.pop(k, None)
         os.environ.update(self.env)
@@ -84,7 +86,7 @@ SHAPES = [  # (A, T, U): one and two states per lane pair, every T parity around
 ]
 
 
-@pytest.mark.parametrize("which", ["fused", "lattice", "generic"])
+@pytest.mark.parametrize("which", ["fused", "fused2w", "lattice", "generic"])
 def test_paths_f64_vs_oracle(mods, which):
     cf, octc, _ = mods
     rs = np.random.RandomState(11)
@@ -99,7 +101,7 @@ def test_paths_f64_vs_oracle(mods, which):
     print("%s: worst float64 gradient error %.1e over %d cases" % (which, worst, len(SHAPES) * 6))
 
 
-@pytest.mark.parametrize("which", ["fused", "generic"])
+@pytest.mark.parametrize("which", ["fused", "fused2w", "generic"])
 def test_paths_quirks(mods, golden, which):
     """the reference's skip / empty band / T = 1 behaviour on the round-5 paths (test_gpu_ctc.py holds the same
     for the default dispatch)"""
@@ -182,7 +184,7 @@ def test_fused_f32_row_store(mods):
         with np.errstate(all="ignore"):
             c_ref, g_ref, s_ref = octc.ctc_loss(np.asfortranarray(y.astype(np.float64)), seq)
         res = {}
-        for which in ("fused", "fused64", "lattice"):
+        for which in ("fused", "fused64", "fused2w", "lattice"):
             with path(which), np.errstate(all="ignore"):
                 cost, grads, skip = cf.ctc_loss_batch([y], [seq])
             assert not skip[0] and not s_ref
@@ -198,7 +200,8 @@ def test_fused_f32_row_store(mods):
 
 def test_fused_ragged_batch_and_long_lists(mods):
     """one launch over utterances of every length (K is chosen by the longest row; short rows sit in its lanes),
-    labels that occur more often than the 8 list entries a lane keeps in registers, float32 and float64"""
+    labels that occur more often than the 8 list entries a lane keeps in registers, float32 and float64; with and
+    without helper waves"""
     cf, octc, _ = mods
     rs = np.random.RandomState(17)
     for A, dt in ((33, np.float64), (3, np.float32), (70, np.float32), (150, np.float64)):
@@ -209,21 +212,25 @@ def test_fused_ragged_batch_and_long_lists(mods):
             y, seq = _case(rs, A, T, U, with_blank_labels=(b % 5 == 0), all_same=(b % 11 == 3))
             probs.append(np.asfortranarray(y.astype(dt)))
             seqs.append(seq)
-        with path("fused"), np.errstate(all="ignore"):
-            cost, grads, skip = cf.ctc_loss_batch(probs, seqs)
+        refs = []
         for b in range(37):
             with np.errstate(all="ignore"):
-                c_ref, g_ref, s_ref = octc.ctc_loss(np.asfortranarray(probs[b].astype(np.float64)), seqs[b])
-            assert bool(skip[b]) == bool(s_ref), (A, b)
-            if s_ref:
-                assert not grads[b].any()
-                continue
-            if np.isinf(c_ref):
-                assert np.isinf(cost[b])
-            else:
-                assert abs(cost[b] - c_ref) <= 1e-11 * abs(c_ref), (A, b)
-            tol = 1e-9 if dt == np.float64 else 2e-7
-            assert np.abs(grads[b].astype(np.float64) - g_ref).max() < tol, (A, b, probs[b].shape, len(seqs[b]))
+                refs.append(octc.ctc_loss(np.asfortranarray(probs[b].astype(np.float64)), seqs[b]))
+        for which in ("fused", "fused2w"):
+            with path(which), np.errstate(all="ignore"):
+                cost, grads, skip = cf.ctc_loss_batch(probs, seqs)
+            for b in range(37):
+                c_ref, g_ref, s_ref = refs[b]
+                assert bool(skip[b]) == bool(s_ref), (which, A, b)
+                if s_ref:
+                    assert not grads[b].any()
+                    continue
+                if np.isinf(c_ref):
+                    assert np.isinf(cost[b])
+                else:
+                    assert abs(cost[b] - c_ref) <= 1e-11 * abs(c_ref), (which, A, b)
+                tol = 1e-9 if dt == np.float64 else 2e-7
+                assert np.abs(grads[b].astype(np.float64) - g_ref).max() < tol, (which, A, b, probs[b].shape, len(seqs[b]))
 
 
 def test_long_label_rows_and_wide_alphabets(mods):

@@ -21,13 +21,14 @@ import ctc_fast  # noqa: E402
 
 SHAPES = {"cfg3": (32, 1000, 100, 33), "sat": (4096, 1000, 100, 33), "cfg2": (256, 300, 60, 62),
           "cfg5": (8, 8000, 800, 33), "sat1k": (1024, 1000, 100, 33)}
-PATHS = {"fused": {}, "fused64": {"SCTC_CTC_STORE": "64"}, "lattice": {"SCTC_CTC_FUSED": "0"}}
+PATHS = {"fused": {}, "fused64": {"SCTC_CTC_STORE": "64"}, "fused2w": {"SCTC_CTC_HELPER": "0"},
+         "lattice": {"SCTC_CTC_FUSED": "0"}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="cfg3,sat,cfg5")
-    ap.add_argument("--paths", default="fused,fused64,lattice")
+    ap.add_argument("--paths", default="fused,fused64,fused2w,lattice")
     ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
     for name in args.shapes.split(","):
@@ -40,7 +41,7 @@ def main():
         algo = B * (2 * 4 * A * T + 4 * U + 8)
         ref = None
         for pname in args.paths.split(","):
-            for k in ("SCTC_CTC_STORE", "SCTC_CTC_FUSED"):
+            for k in ("SCTC_CTC_STORE", "SCTC_CTC_FUSED", "SCTC_CTC_HELPER"):
                 os.environ.pop(k, None)
             os.environ.update(PATHS[pname])
             cost, grad, skip = ctc_fast.ctc_loss_batch(probs, seqs, lengths=[T] * B)     # warm-up (allocator, code objects)
