@@ -17,7 +17,7 @@ import os
 import sys
 from collections import defaultdict
 
-FAMILIES = ["gemm_f32_kernel", "brnn_recurrent", "ctc_lattice_kernel", "ctc_grad_kernel",
+FAMILIES = ["gemm_f32_kernel", "brnn_recurrent", "ctc_fused_kernel", "ctc_lattice_kernel", "ctc_grad_kernel",
             "softmax_rows_kernel", "splitk_reduce_kernel", "colsum_partial_kernel",
             "colsum_final_kernel", "add_kernel", "gather_rows_kernel", "scatter_rows_kernel"]
 
@@ -63,9 +63,11 @@ def main(root):
     out = {"source": "rocprofv3 --kernel-trace --stats and three separate --pmc passes of "
                      "`python bench.py --no-side --no-cpu-baseline` (tools/profile_bench.sh)",
            "units": {"fetch/write": "bytes per launch (rocprofv3 KiB x 1024)"}, "kernels": {}}
-    steps_stats = st.get("ctc_lattice_kernel", {}).get("calls", 0)
-    steps_pmc = len(mf.get("ctc_lattice_kernel", {}).get("SQ_WAVES", [])) or \
-        len(fe.get("ctc_lattice_kernel", {}).get("FETCH_SIZE", []))
+    # one softmax_rows launch per costAndGrad (round 5: the CTC kernel of a step is ctc_fused_kernel OR the
+    # ctc_lattice / ctc_grad pair, the softmax is always there)
+    steps_stats = st.get("softmax_rows_kernel", {}).get("calls", 0)
+    steps_pmc = len(mf.get("softmax_rows_kernel", {}).get("SQ_WAVES", [])) or \
+        len(fe.get("softmax_rows_kernel", {}).get("FETCH_SIZE", []))
     out["costAndGrad_calls"] = {"stats_pass": steps_stats, "pmc_passes": steps_pmc}
     if len(sys.argv) > 2:
         out["source_hash"] = sys.argv[2]      # bench.csrc_hash() of the measured tree

@@ -178,7 +178,12 @@ __device__ __forceinline__ void wait_all(unsigned* flags, int nwg, unsigned targ
 
 // NTW: utterance tiles (16 each) per wave.  NCHH: 16-unit K chunks per wave when known at
 // compile time (Hp == 32*NCHH: fully unrolled, branch-free), 0 = run-time loop.
-template <int NTW, int NCHH>
+// PIPE (round 5, NCHH > 0 only): the exchange loads of batch k+1 are issued before the MFMAs of batch k (two
+// half-size batches in flight, the compiler's counted s_waitcnt vmcnt in front of each batch's first MFMA) instead
+// of all loads of a batch, a fence, then its MFMAs: at 64 / 128 utterances a step is 7 / 14 us of matrix work and
+// 3.5 / 7 us of exchange traffic through the CU's one vector-memory pipe, which used to run one after the other.
+// Same MFMAs on the same accumulators in the same order: bit-identical results.
+template <int NTW, int NCHH, bool PIPE = false>
 __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
@@ -233,6 +238,11 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
         uT[i] = ub[i] < p.B ? p.T_b[ub[i]] : 0;
     }
     const int c_beg = kh * nch_half, c_end = c_beg + nch_half;
+    // Which K half adds the other's partial sums to its own and stores the step's result of tile i.  Rounds 1-4: the
+    // lower half, every tile (the upper half's waves sat out the epilogue: 1.8 us of a 128-utterance step).  Round 5:
+    // the halves take alternate tiles -- own + other is the same float addition either way round, bit-identical.
+    const bool split_epilogue = NTW >= 2 && p.variant != 40;
+    auto finishes = [&](int i) -> bool { return split_epilogue ? ((i & 1) == kh) : (kh == 0); };
 
     const int dbg_sel = (p.debug && g == 0 && tid == 0) ? (wg == 0 ? 0 : (wg == nwg - 1 ? 1 : -1)) : -1;
     auto stamp = [&](int j, int k) {
@@ -271,11 +281,11 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
         }
         // prefetch the per-frame additive term (independent of the recurrence)
         float4 pre4[NTW], act4[NTW];
-        if (kh == 0) {
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) {
-                pre4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                act4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < NTW; ++i) {
+            pre4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            act4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (finishes(i)) {
                 if (active[i]) {
                     pre4[i] = *reinterpret_cast<const float4*>(pre + orow[i] * ld + row0 + 4 * kq);
                     if (act) act4[i] = *reinterpret_cast<const float4*>(act + orow[i] * ld + row0 + 4 * kq);
@@ -288,7 +298,38 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
             stamp(j, 1);
             // All x loads of a batch are issued, unconditionally, before its first MFMA
             // (up to 64 float4 = 256 VGPRs per lane): one latency + streaming per step.
-            if constexpr (NCHH > 0) {
+            if constexpr (NCHH > 0 && PIPE) {
+                constexpr int XB = NCHH < 32 / NTW ? NCHH : 32 / NTW;     // chunks per batch; two batches of registers
+                constexpr int NBAT = (NCHH + XB - 1) / XB;
+                float4 x[2][XB][NTW];
+#pragma unroll
+                for (int u = 0; u < XB; ++u)
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i) x[0][u][i] = ld_x(xrsrc, xin[i], (unsigned)(c_beg + u) * chunk_stride);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int bi = 0; bi < NBAT; ++bi) {
+                    if (bi + 1 < NBAT) {
+#pragma unroll
+                        for (int u = 0; u < XB; ++u)
+                            if ((bi + 1) * XB + u < NCHH) {
+#pragma unroll
+                                for (int i = 0; i < NTW; ++i)
+                                    x[(bi + 1) & 1][u][i] = ld_x(xrsrc, xin[i], (unsigned)(c_beg + (bi + 1) * XB + u) * chunk_stride);
+                            }
+                    }
+                    // the next batch's loads stay in front of this batch's MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < XB; ++u)
+                        if (bi * XB + u < NCHH) {
+                            const float4 a = Wl[(c_beg + bi * XB + u) * 64 + lane];
+#pragma unroll
+                            for (int i = 0; i < NTW; ++i) { SCTC_MFMA4(acc[i], a, x[bi & 1][u][i]) }
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (NCHH > 0) {
                 constexpr int XB = NCHH < 64 / NTW ? NCHH : 64 / NTW;
 #pragma unroll
                 for (int cb = 0; cb < NCHH; cb += XB) {
@@ -338,10 +379,10 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
                 asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));
                 stamp(j, 2);
             }
-            // fold the two K halves: upper half parks its partials in LDS
-            if (kh == 1) {
+            // fold the two K halves: a wave parks the partials of the tiles the OTHER half finishes in LDS
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) {
+            for (int i = 0; i < NTW; ++i) {
+                if (!finishes(i)) {
                     f32x4 s = (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
                     red[(ng * NTW + i) * 64 + lane] = make_float4(s[0], s[1], s[2], s[3]);
                 }
@@ -350,10 +391,10 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
             stamp(j, 3);
         }
 
-        if (kh == 0) {
+        {
 #pragma unroll
             for (int i = 0; i < NTW; ++i) {
-                if (!active[i]) continue;
+                if (!finishes(i) || !active[i]) continue;
                 float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (j > 0) {
                     const float4 r = red[(ng * NTW + i) * 64 + lane];
@@ -1511,8 +1552,22 @@ int recurrent_supported(int Hp, int B, char* why, int why_len)
 }
 
 template <int NTW>
-static RecKernel pick_kernel(int nch_half)
+static RecKernel pick_kernel(int nch_half, bool pipe)
 {
+    // two utterance tiles per wave (33..64 utterances) keep the round 1-4 order: there the loads of the second
+    // (last) batch are the only ones not under MFMAs, and the pipelined order measured SLOWER (13.1 -> 14.7 us per step
+    // at 64 utterances; 24.6 -> 21.6 at 128: profiles/r05_recurrence_large.md)
+    if constexpr (NTW >= 4) {
+        if (pipe) {
+            switch (nch_half) {
+                case 16: return brnn_recurrent_kernel<NTW, 16, true>;   // H = 512
+                case 32: return brnn_recurrent_kernel<NTW, 32, true>;   // H = 1024
+                case 57: return brnn_recurrent_kernel<NTW, 57, true>;   // H = 1824
+                case 64: return brnn_recurrent_kernel<NTW, 64, true>;   // H = 2048
+                default: break;
+            }
+        }
+    }
     switch (nch_half) {
         case 16: return brnn_recurrent_kernel<NTW, 16>;   // H = 512
         case 32: return brnn_recurrent_kernel<NTW, 32>;   // H = 1024
@@ -1966,8 +2021,9 @@ static int launch_recurrent_one(const RecArgs& a, const LaunchCtx& cx)
     const int ntw = ntiles <= 2 ? 1 : (ntiles <= 4 ? 2 : 4);
     const size_t smem = sizeof(float4) * ((size_t)nwg * 64 + 2 * ntw * 64);
     if (smem <= 160 * 1024) {
-        RecKernel kern = ntw == 1 ? pick_kernel<1>(nwg / 2)
-                         : (ntw == 2 ? pick_kernel<2>(nwg / 2) : pick_kernel<4>(nwg / 2));
+        const bool pipe = a.variant != 40;     // 40: exchange loads and MFMAs of a batch one after the other (rounds 1-4; A/B)
+        RecKernel kern = ntw == 1 ? pick_kernel<1>(nwg / 2, false)
+                         : (ntw == 2 ? pick_kernel<2>(nwg / 2, pipe) : pick_kernel<4>(nwg / 2, pipe));
         SCTC_TRY(launch_persistent(kern, 2 * nwg, smem, 1, 0, a, cx, &done));
         if (done) return SCTC_OK;
     }

@@ -593,6 +593,7 @@ def main():
              "brnn": lambda: sec_brnn("cfg3", 32, 0),
              "brnn1": lambda: sec_brnn("cfg3", 32, 1),
              "recdbg": lambda: sec_recdbg(0), "recdbg1": lambda: sec_recdbg(1), "recdbgB1": lambda: sec_recdbg(1, 1),
+             "recdbg64": lambda: sec_recdbg(1, 64), "recdbg128": lambda: sec_recdbg(1, 128),
              "brnn_small": lambda: sec_brnn("cfg2", 1, 0),
              "brnn4": lambda: sec_brnn("cfg4", 32, None),
              "brnn5": lambda: sec_brnn("cfg5", 1, None), "brnn5b": lambda: sec_brnn("cfg5", 8, None),
