@@ -130,18 +130,24 @@ def shared_device_from_ids(ids, rank):
     return sum(1 for x in ids if tuple(x) == me) > 1
 
 
-def resolve_shared_device(group=None, my_id=None, log=True):
+def resolve_shared_device(group=None, my_id=None, log=True, device=None):
     """Shared-device mode decided by PHYSICAL device identity: every rank
-    contributes (hostname, PCI bus id of its current device) to an all-gather over the process
-    group; the mode is on iff two ranks report the same pair, whatever device ordinals, visibility
+    contributes (hostname, PCI bus id of its device) to an all-gather over the process group; the
+    mode is switched ON iff two ranks report the same pair, whatever device ordinals, visibility
     masks or LOCAL_WORLD_SIZE say.  An explicit SCTC_SHARED_DEVICE in the environment wins.
-    Returns (shared, ids).  One line per rank on stderr."""
+    `device`: the HIP device ordinal the rank's model lives on (dist_sgd.DataParallel passes the device of
+    the net's gradient buffer); None = the current device -- which is device 0 on every rank that has
+    not called torch.cuda.set_device yet, and then every rank would report the same GPU.
+    This function only ever RAISES the mode: a mode that a timeout or the per-device activity markers of
+    a foreign process switched on earlier stays on.  NOTE: it is a COLLECTIVE over `group` (an
+    all_gather_object): every rank must call it, at the same point -- DataParallel() does, in its
+    constructor.  Returns (shared, ids).  One line per rank on stderr."""
     import socket
     import sys
     import torch.distributed as dist
     L = lib()
     if my_id is None:
-        my_id = (socket.gethostname(), device_bus_id())
+        my_id = (socket.gethostname(), device_bus_id(-1 if device is None else int(device)))
     rank, ids = 0, [tuple(my_id)]
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         rank = dist.get_rank(group)
@@ -152,7 +158,11 @@ def resolve_shared_device(group=None, my_id=None, log=True):
         shared, why = bool(L.sctc_shared_device()), "SCTC_SHARED_DEVICE in the environment"
     else:
         shared, why = shared_device_from_ids(ids, rank), "bus ids of %d rank(s)" % len(ids)
-        L.sctc_set_shared_device(1 if shared else 0)
+        if shared:
+            L.sctc_set_shared_device(1)
+        elif L.sctc_shared_device():
+            why += "; the mode was already on (a timeout or another process on this GPU) and stays on"
+            shared = True
     if log:
         sys.stderr.write("sctc: rank %d -> %s %s, shared=%d (%s)\n"
                          % (rank, my_id[0], my_id[1], int(shared), why))

@@ -1,7 +1,8 @@
 // 16-bit-operand GEMM staged by LDS-DMA (round 4): the contractions of the "fp16 activations"
 // configuration (BASELINE configs[4]; brnnet.py:140 fwd, :196 wgrad, :204 dgrad, :227-230 recurrent
 // wgrad) on operands that are ALREADY 16-bit in memory (the shadow copies their producers write),
-// 256 x 256 output tiles, K tile 64, one block of 8 waves (2 x 4, 128 x 64 per wave) per CU.
+// 256 x 256 output tiles, K tile 32 (G_BK; four LDS stages of 2 x 16 KiB), one block of 8 waves (2 x 4, 128 x 64 per
+// wave) per CU.
 //
 // What round 2's gemm_x16_kernel (gemm_h16.hip) was bound by -- its ablation: MFMAs + fragment reads
 // 0.82 ms, + LDS stores and barrier 1.06 ms, + global loads 2.10 ms at 8192^3 -- is the operand path
@@ -12,10 +13,10 @@
 //     MFMAs of tile t and waited for once, in front of the tile's one barrier.
 //   * the LDS image is unpadded and XOR-swizzled; because the LDS side of a glds is lane-linear the
 //     swizzle is applied to the lane's SOURCE address and undone by the fragment reads:
-//       K-contiguous operands (forward, delta propagation with W^T): image [row][8 x 16 B], the 16-byte
-//         k-slot s of row r sits at slot s ^ ((r >> 1) & 7).  Eight consecutive lanes fetch one full
-//         128-byte line; a fragment (lane l: row l & 31, 8 k at slot 2 kk + (l >> 5)) is ONE
-//         ds_read_b128 whose 16-lane groups cover the 64 banks exactly once.
+//       K-contiguous operands (forward, delta propagation with W^T): image [row][4 x 16 B] (a K tile of 32
+//         16-bit values is 64 bytes per row), the 16-byte k-slot s of row r sits at slot s ^ ((r >> 2) & 3).
+//         Four consecutive lanes fetch one 64-byte row segment; a fragment (lane l: row l & 31, 8 k at
+//         slot 2 kk + (l >> 5)) is ONE ds_read_b128 whose 16-lane groups cover the 64 banks exactly once.
 //       row-contiguous operands (weight gradients, [k][m] in memory): image [k][32 x 16 B] (512-byte
 //         k-rows, straight copy), the 16-byte m-piece q of k-row k at piece q ^ ((k & 3) << 2).  32
 //         consecutive lanes fetch 512 contiguous bytes.  MFMA fragments need 8 consecutive k per
@@ -355,8 +356,12 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_g16_kernel(GemmArgs p)
         //     same moment, with the matrix pipe idle.
         //     Hazards (lead = one interval): a stage is refilled (tile t + 3 -> the stage of tile t - 1)
         //     in mem(t); the other group read tile t - 1 in ITS mem(t - 1), which ended at a barrier
-        //     before that.  Tile t + 1 is read in mem(t + 1); both groups wait for their own pieces of it
-        //     at the end of their mem(t), and at least one barrier lies in between.
+        //     before that -- and a raw s_barrier does not wait for LDS reads in flight, so the wait in front
+        //     of that barrier names lgkmcnt(0) as well (until round 5 the fragment reads were only
+        //     waited for behind the barrier, in front of the MFMAs, and the refill's safety rested on a
+        //     global load taking longer than the LDS read queue).  Tile t + 1 is read in mem(t + 1); both
+        //     groups wait for their own pieces of it at the end of their mem(t), and at least one barrier
+        //     lies in between.
         const bool late = wm == 1;                 // wave-uniform (scalar branch)
         stage(kt_beg);
         stage(kt_beg + 1);
@@ -373,7 +378,8 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_g16_kernel(GemmArgs p)
             if (do_colsum) colsum(st);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(G_ABL & 8)) {
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's pieces of tile kt + 1 are in LDS
+                // this wave's pieces of tile kt + 1 are in LDS, its fragment reads of tile kt have returned
+                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -1642,14 +1642,15 @@ struct DeviceLease {      // inter-process: one lock file per physical device
         for (int k = 0; k < 2 && fd < 0; ++k) {
             snprintf(path, sizeof(path), "%s/sctc_gpu_%s.lock", dirs[k], bus);
             // the name is predictable and the directory world-writable: never follow a planted symlink,
-            // never touch the mode of anything but a regular file we may have just created (the file
-            // is created world-read/writable under a cleared umask instead of being fchmod'ed)
-            const mode_t um = umask(0);
+            // never touch the mode of anything but a regular file of our own
+            // the process umask is left alone (another thread creating a file at that moment would inherit a
+            // cleared one: ADVICE r04): the mode is widened on the DESCRIPTOR, and only of a regular file this
+            // user owns (O_NOFOLLOW: never through a planted symlink)
             fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
-            (void)umask(um);
             if (fd >= 0) {
                 struct stat st;
                 if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); fd = -1; }
+                else if (st.st_uid == geteuid() && (st.st_mode & 0666) != 0666) (void)fchmod(fd, 0666);
             }
         }
         fds[dev] = fd;
@@ -1668,13 +1669,23 @@ struct LeaseGuard {
         if (fd >= 0) {
             // bounded: another user holding the lock for good must not hang this process with its
             // mutex held -- after LEASE_WAIT_S the caller runs the step on the per-step fallback
+            // Polling with a growing back-off (200 us .. 5 ms) instead of a blocking flock: the wait must end, and a
+            // waiter that polls every 200 us re-acquires ahead of one that slept longer -- so every rank backs off the
+            // same way and a rank that has just held the lease yields once (below) before it asks again.
             const double t0 = now_s();
+            useconds_t nap = 200;
             for (;;) {
                 const int rc = flock(fd, LOCK_EX | LOCK_NB);
                 if (rc == 0) { locked = true; break; }
                 if (errno != EWOULDBLOCK && errno != EINTR) break;
-                if (now_s() - t0 > LEASE_WAIT_S) break;
-                usleep(200);
+                if (now_s() - t0 > LEASE_WAIT_S) {
+                    // not silent: the step falls back to one launch per time step
+                    fprintf(stderr, "sctc: device lease not obtained within %.0f s (another process holds %s): this step "
+                                    "runs on the per-step recurrent kernels\n", LEASE_WAIT_S, "the GPU's persistent-launch lock");
+                    break;
+                }
+                usleep(nap);
+                if (nap < 5000) nap += nap / 2;
             }
         }
     }
@@ -1696,6 +1707,7 @@ struct LeaseGuard {
 // 1, 2, 4, ... 32 and every 32nd after that (a directory scan of /dev/shm, ~20 us) while the mode is
 // off; ranks that exchange their bus ids over a process group (dist_sgd.DataParallel) decide at once.
 static constexpr double USER_ACTIVE_S = 0.3;     // a marker untouched for this long belongs to an idle process (a trainer launches every few ms)
+static constexpr double MARKER_STALE_S = 2.0;   // an UNLOCKED marker older than this is a dead process's
 struct DeviceUsers {
     std::mutex mu;
     std::map<int, std::pair<int, std::string>> mine;    // device -> (held marker fd, marker prefix)
@@ -1714,7 +1726,14 @@ struct DeviceUsers {
                 struct timespec now;
                 clock_gettime(CLOCK_REALTIME, &now);
                 held = errno == EWOULDBLOCK && (double)(now.tv_sec - st.st_mtim.tv_sec) + 1e-9 * (double)(now.tv_nsec - st.st_mtim.tv_nsec) < USER_ACTIVE_S;
-            } else { (void)unlink(path); (void)flock(fd, LOCK_UN); }      // stale: its owner is gone
+            } else {
+                // unlocked: its owner is gone -- or has created it a moment ago and not locked it yet (create and
+                // lock are two calls): only a marker that has been lying there for a while is removed
+                struct timespec now;
+                clock_gettime(CLOCK_REALTIME, &now);
+                if ((double)(now.tv_sec - st.st_mtim.tv_sec) > MARKER_STALE_S) (void)unlink(path);
+                (void)flock(fd, LOCK_UN);
+            }
         }
         close(fd);
         return held;
@@ -1730,12 +1749,21 @@ struct DeviceUsers {
             for (char* c = bus; *c; ++c)
                 if (*c == ':' || *c == '.' || *c == '/') *c = '_';
             std::string prefix = std::string("sctc_gpu_") + bus + ".user.";
-            const std::string path = "/dev/shm/" + prefix + std::to_string((long)getpid());
-            const mode_t um = umask(0);
+            it = mine.emplace(dev, std::make_pair(-1, prefix)).first;
+        }
+        if (it->second.first < 0) {
+            // (re)create the marker: a failed attempt -- or a marker a scanner removed between our open() and
+            // flock() -- is tried again at the next check instead of leaving this process invisible for good
+            const std::string path = "/dev/shm/" + it->second.second + std::to_string((long)getpid());
             int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
-            (void)umask(um);
-            if (fd >= 0 && flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); fd = -1; }
-            it = mine.emplace(dev, std::make_pair(fd, prefix)).first;
+            struct stat st, on_disk;
+            if (fd >= 0 && (flock(fd, LOCK_EX | LOCK_NB) != 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) ||
+                            stat(path.c_str(), &on_disk) != 0 || on_disk.st_ino != st.st_ino)) {
+                close(fd);      // not lockable, or the name no longer leads to the file we hold
+                fd = -1;
+            }
+            if (fd >= 0 && st.st_uid == geteuid() && (st.st_mode & 0666) != 0666) (void)fchmod(fd, 0666);
+            it->second.first = fd;
         }
         if (it->second.first < 0) return 0;
         int n = 1;

@@ -117,8 +117,12 @@ class DataParallel(object):
         # one GPU must take the device lease around their persistent recurrent launches, eight on eight
         # GPUs must NOT (it would drain the stream around every launch and serialise the overlapped
         # all-reduce), whatever HIP_VISIBLE_DEVICES / LOCAL_WORLD_SIZE look like
+        # (a COLLECTIVE over `group`: every rank constructs its DataParallel at the same point; the device is the one
+        # the net's gradient buffer lives on, not whatever the current device happens to be)
         import _sctc
-        self.shared_device, self.device_ids = _sctc.resolve_shared_device(group)
+        dev = getattr(getattr(net, "grad", None), "flat", None)
+        dev = dev.device.index if dev is not None and getattr(dev, "is_cuda", False) else None
+        self.shared_device, self.device_ids = _sctc.resolve_shared_device(group, device=dev)
 
     def allreduce_gradients(self, n_valid_local, cost_sum_local=0.0, regcost_local=None):
         """after net.costAndGradBatch on every rank: sums gradients, utterance counts and costs

@@ -177,6 +177,11 @@ def _world8_worker(rank, world, port, out):
     bus = 0x10 + (2 if rank == 5 else rank)
     shared_b, ids_b = _sctc.resolve_shared_device(my_id=("node0", "0000:%02x:00.0" % bus), log=False)
     mode_b = L.sctc_shared_device()
+    # (2b) the exchange only ever RAISES the mode: ranks 2 and 5, switched on above, stay on when a
+    # later exchange sees eight distinct devices -- a timeout or a foreign process may have been the reason
+    shared_b2, _ = _sctc.resolve_shared_device(my_id=("node0", "0000:%02x:00.0" % (0x10 + rank)), log=False)
+    assert shared_b2 == (rank in (2, 5)) and bool(L.sctc_shared_device()) == (rank in (2, 5))
+    L.sctc_set_shared_device(0)
     # (3) the same bus id on two different HOSTS is not sharing
     shared_c, _ = _sctc.resolve_shared_device(my_id=("node%d" % rank, "0000:10:00.0"), log=False)
     L.sctc_set_shared_device(0)
