@@ -81,6 +81,10 @@ int ctc_make_plan(int B, int A, int blank, int dtype, const int32_t* T_b, const 
         return SCTC_OK;
     }
     plan->lat_elems = frames * plan->lp;
+    if (plan->generic) {    // per-utterance row strides (ctc_generic.hip)
+        plan->lat_elems = 0;
+        for (int b = 0; b < B; ++b) plan->lat_elems += (int64_t)T_b[b] * round_up(2 * U_b[b] + 2, 64);
+    }
     // labels, the same labels grouped by value (ctc_grad's per-label sums), group offsets
     plan->bytes = head + align256(sizeof(double) * 2 * B) + align256(sizeof(int32_t) * 2 * B) +
                   2 * align256(sizeof(double) * plan->lat_elems) +
@@ -154,7 +158,8 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
         for (int k = 0; k < plan.A; ++k) start[k + 1] += start[k];
         st.cursor.assign(start, start + plan.A);
         for (int i = 0; i < u.U; ++i) grouped[st.cursor[src[i]]++] = 2 * i + 1;
-        lat_off += plan.fused ? plan.K + (int64_t)u.T * round_up(2 * u.U + 1, plan.K) : (int64_t)u.T * plan.lp;
+        lat_off += plan.fused ? plan.K + (int64_t)u.T * round_up(2 * u.U + 1, plan.K)
+                              : (plan.generic ? (int64_t)u.T * round_up(2 * u.U + 2, 64) : (int64_t)u.T * plan.lp);
         lab_off += u.U;
     }
     const size_t utt_bytes = sizeof(CtcUtt) * plan.B, utt_span = align256(utt_bytes), lab_bytes = sizeof(int32_t) * n_int;

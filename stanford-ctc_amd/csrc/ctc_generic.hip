@@ -68,9 +68,11 @@ __global__ __launch_bounds__(GEN_NT) void ctc_lattice_generic_kernel(CtcLatticeA
     __shared__ double red[2][GEN_NW];
     const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
     const CtcUtt u = p.utts[b];
-    const int T = u.T, U = u.U, L = 2 * U + 1, LP = p.lp;
+    const int T = u.T, U = u.U, L = 2 * U + 1;
+    const int LP = (L + 1 + 63) / 64 * 64;      // this utterance's lattice row stride (a batch with ONE long label row
+                                                // does not pay its width for every utterance); p.lp = the widest
     double* lat = (dir == 0 ? p.alpha : p.beta) + u.lat_off;
-    double* sc = p.scratch + (int64_t)(2 * b + dir) * 2 * LP;
+    double* sc = p.scratch + (int64_t)(2 * b + dir) * 2 * p.lp;
     const int32_t* seq = p.labels + u.lab_off;
     const int blank = p.blank;
     // label of the odd state s of MY direction's row (beta: the reversed label sequence)
@@ -106,8 +108,8 @@ __global__ __launch_bounds__(GEN_NT) void ctc_lattice_generic_kernel(CtcLatticeA
     }
     __syncthreads();
     for (int tau = 1; tau < T && !skip; ++tau) {
-        const double* prev = sc + (int64_t)((tau - 1) & 1) * LP;
-        double* cur = sc + (int64_t)(tau & 1) * LP;
+        const double* prev = sc + (int64_t)((tau - 1) & 1) * p.lp;
+        double* cur = sc + (int64_t)(tau & 1) * p.lp;
         const RI* y = probs_row(tau);
         const double yb = (double)y[blank];
         // lower band limit, ctc_fast.pyx:49-53; states >= end come out as exact zeros
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void ctc_grad_generic_kernel(CtcGradArgs<RI> p
     __shared__ double red[2][4];
     const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
     const CtcUtt u = p.utts[b];
-    const int T = u.T, U = u.U, L = 2 * U + 1, LP = p.lp, A = p.A, blank = p.blank;
+    const int T = u.T, U = u.U, L = 2 * U + 1, LP = (L + 1 + 63) / 64 * 64, A = p.A, blank = p.blank;
     if (t >= T) return;
     const int skip = p.skip2[2 * b] | p.skip2[2 * b + 1];
     if (t == 0 && tid == 0) {

@@ -24,7 +24,19 @@ import numpy as np
 import _sctc
 import dist_sgd
 
-MAX_LATTICE_STATES = 2048      # 2U+1 limit of the CTC lattice kernels (csrc/capi_ctc.hip)
+LATTICE_STATES_RESERVED = 2048  # lattice row the engine's workspace reserves per frame (csrc/brnn_engine.hip CTC_LP_MAX)
+
+
+def lattice_fits(T, U, max_frames):
+    """Round 5: label rows of any length run (ctc_generic.hip beyond 2U+1 = 2048, like the reference, which has no
+    bound: ctc_fast.pyx:22-32).  What is left is the workspace the model was created with: it reserves 2048 lattice
+    states for each of its maxBatch frames per utterance slot, so a longer label row fits while T x round_up(2U+2,
+    64) stays within that share (a 3001-state row fits an utterance of up to two thirds of maxBatch frames)."""
+    L = 2 * U + 1
+    if L <= LATTICE_STATES_RESERVED:
+        return True
+    w = (L + 1 + 63) // 64 * 64
+    return (T + 2) * w <= (max_frames + 2) * LATTICE_STATES_RESERVED
 
 
 class SGD:
@@ -152,9 +164,10 @@ class SGD:
                 logging.info("SKIPPING utt frames less than label length (Utterance length %d, "
                              "Num Labels %d)." % (mb_data.shape[1], mb_labels.shape[0]))
                 continue
-            # conditions the engine rejects with ValueError (the reference would index out of
-            # bounds / has no lattice-width limit): one bad utterance must not end the run
-            if mb_labels.shape[0] < 1 or 2 * mb_labels.shape[0] + 1 > MAX_LATTICE_STATES or \
+            # conditions the engine rejects (the reference would index out of bounds; a label row beyond 2048
+            # states that does not fit the workspace share of its utterance slot): one bad utterance must not
+            # end the run
+            if mb_labels.shape[0] < 1 or not lattice_fits(mb_data.shape[1], mb_labels.shape[0], self.maxBatch) or \
                     mb_labels.min() < 0 or mb_labels.max() >= self.model.outputDim:
                 logging.info("SKIPPING utt with unusable labels (Num Labels %d, ids %s..%s)."
                              % (mb_labels.shape[0], mb_labels.min() if mb_labels.size else '-',

@@ -272,3 +272,35 @@ def test_wide_alphabet_through_the_network(mods):
     for (dw, db), gw, gb in zip(grad[:NL + 1], g_ref["W"], g_ref["b"]):
         assert np.linalg.norm(dw.copy_to_host() - gw) <= 1e-4 * np.linalg.norm(gw) + 1e-7
         assert np.linalg.norm(db.copy_to_host().ravel() - gb.ravel()) <= 1e-4 * np.linalg.norm(gb) + 1e-7
+
+
+def test_long_label_row_through_the_network_and_the_trainer_check(mods):
+    """NNet.costAndGrad on an utterance whose label row has 2201 lattice states (rounds 1-4: SCTC_ERR_ARG, the trainer
+    skipped it): cost and gradients against the float64 oracle; sgd.lattice_fits says what the workspace share of an
+    utterance slot holds"""
+    cf, octc, torch = mods
+    from nnets import brnnet
+    from oracle import brnn as obrnn
+    import sgd
+    D, A, H, NL, TL, T, U, maxBatch = 8, 20, 32, 2, 1, 1300, 1100, 2000
+    assert sgd.lattice_fits(T, U, maxBatch) and sgd.lattice_fits(8000, 800, 8000)
+    assert not sgd.lattice_fits(2000, 1100, maxBatch) and sgd.lattice_fits(2000, 1023, maxBatch)
+    rs = np.random.RandomState(8)
+    data = rs.randn(D, T)
+    labels = rs.randint(1, A, size=U).astype(np.int32)
+    np.random.seed(3)
+    net = brnnet.NNet(D, A, H, NL, maxBatch, temporalLayer=TL)
+    net.initParams()
+    np.random.seed(3)
+    params = obrnn.init_params(D, A, H, NL, TL)
+    cost, grad, skip = net.costAndGrad(data, labels)
+    with np.errstate(all="ignore"):
+        c_ref, g_ref, s_ref, _ = obrnn.cost_and_grad(params, data, labels, TL, max_act=20.0)
+    assert not skip and not s_ref
+    assert abs(cost - c_ref) <= 1e-4 * abs(c_ref), (cost, c_ref)
+    for (dw, db), gw in zip(grad[:NL + 1], g_ref["W"]):
+        assert np.linalg.norm(dw.copy_to_host() - gw) <= 2e-4 * np.linalg.norm(gw) + 1e-7
+    # a row that does not fit the share is a workspace error of the library, not a wrong answer
+    import _sctc
+    with pytest.raises((_sctc.SctcError, ValueError)):
+        net.costAndGrad(rs.randn(D, 2000), rs.randint(1, A, size=1100).astype(np.int32))
