@@ -44,6 +44,10 @@
 // order: differences are in the last bits, the float64 golden vectors hold at 1e-11 / 1e-9).
 #include <type_traits>
 
+#ifndef SCTC_FUSED_PF2
+#define SCTC_FUSED_PF2 4
+#endif
+
 #include "common.h"
 #include "ctc_kernels.h"
 #include "xlane.h"
@@ -94,7 +98,9 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
     // prefetched a block ahead, a block's rows are stored / its gradient rows finished behind its last
     // frame, so that the frames themselves are ONE basic block without a store or a branch: whatever
     // does not feed the recursion is scheduled into the gaps of its dependency chain.
-    constexpr int PF = 8;
+    // (two-wave form: 4 -- 190 instead of 296 registers, two waves per SIMD instead of one: 4.1 -> 3.5 ms at 4096
+    // utterances; it is the form of the batches that fill the device)
+    constexpr int PF = HELP ? 8 : SCTC_FUSED_PF2;
     constexpr int NI = NA == 1 ? 8 : 4;     // list entries of a label summed unconditionally
     constexpr int NI2 = NA == 1 ? 16 : NI;  // list entries kept in registers (those beyond NI: summed when some list is that long)
     constexpr int NPOS = 64 * KH;           // label positions of one direction; slot NPOS holds 0.0
@@ -859,12 +865,13 @@ template <typename RI, typename ST, int K>
 static int launch_fused_k(const CtcFusedArgs<RI>& a, int B, int NA, hipStream_t stream)
 {
     // Helper waves (six waves per utterance) while the batch leaves SIMDs idle; beyond SCTC_CTC_HELPER_MAX_B
-    // utterances (default 512: two workgroups per CU) the two-wave form keeps more utterances resident.  Alphabets
+    // utterances (default 256: one six-wave workgroup per CU) the two-wave form keeps more utterances resident
+    // (four workgroups per CU; 4096 utterances of the cfg-3 shape: 3.5 ms against 4.5).  Alphabets
     // of more than 128 symbols (four probability registers per frame) always take the two-wave form: the helper's
     // register budget is 256.  SCTC_CTC_HELPER=0 / 1 forces one form (A/B, tests).
     const char* hz = getenv("SCTC_CTC_HELPER");
     const char* mz = getenv("SCTC_CTC_HELPER_MAX_B");
-    const int max_b = mz ? atoi(mz) : 512;
+    const int max_b = mz ? atoi(mz) : 256;
     const bool help = NA <= 2 && (hz ? atoi(hz) != 0 : B <= max_b);
     if (help) return launch_fused_kh<RI, ST, K, true>(a, B, NA, stream);
     return launch_fused_kh<RI, ST, K, false>(a, B, NA, stream);
