@@ -638,6 +638,7 @@ def ctc_saturation(out, torch, A, T, U):
     """roofline_ctc beside the headline minibatch: the CTC kernels alone at the batch that
     saturates them (4096 utterances of the cfg-3 shape), float32 probabilities on the device"""
     import ctc_fast
+    import _sctc
     B = 4096
     g = torch.Generator(device="cuda")
     g.manual_seed(7)
@@ -646,15 +647,26 @@ def ctc_saturation(out, torch, A, T, U):
     seqs = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
     ctc_fast.ctc_loss_batch(probs, seqs, lengths=[T] * B)
     torch.cuda.synchronize()
+    # (a) the Python entry as a caller uses it; (b) the C entry alone on prepared host arrays, between two events:
+    # descriptor build + pinned upload + kernel
     best_wall, best_gpu = 1e9, 1e9
+    labels = np.concatenate(seqs)
+    U_b = np.full(B, U, dtype=np.int32)
+    T_b = np.full(B, T, dtype=np.int32)
+    label_off = (np.arange(B, dtype=np.int64) * U)
+    frame_off = (np.arange(B, dtype=np.int64) * T)
+    grad = torch.empty_like(probs)
     for _ in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        e0.record()
         ctc_fast.ctc_loss_batch(probs, seqs, lengths=[T] * B)
-        e1.record()
         torch.cuda.synchronize()
         best_wall = min(best_wall, time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ctc_fast._run_batch(probs, grad, A, probs.shape[1], 0, T_b, U_b, frame_off, labels, label_off, _sctc.F32)
+        e1.record()
+        torch.cuda.synchronize()
         best_gpu = min(best_gpu, e0.elapsed_time(e1) * 1e-3)
     byts = B * (2 * 4 * A * T + 4 * U + 8)
     out["roofline_ctc"]["saturating_batch"] = {
@@ -662,10 +674,11 @@ def ctc_saturation(out, torch, A, T, U):
         "frac": byts / best_gpu / 1e9 / PEAK_HBM_GBPS,
         "ms_wall": best_wall * 1e3, "achieved_wall": byts / best_wall / 1e9,
         "note": "ctc_fused_kernel (two waves per utterance at this batch) on 4096 utterances of T=%d U=%d, float32 "
-                "probabilities resident on the device: `ms` between two events around the call (descriptor upload + "
-                "kernel), `ms_wall` adds the Python wrapper (4096 label arrays -> descriptors; rounds 1-4 reported that "
-                "one: 11.4 ms with the three-kernel path).  The float64 recursion is latency/issue-bound, not HBM-bound "
-                "(DESIGN.md 4.3)" % (T, U)}
+                "probabilities resident on the device: `ms` between two events around the C entry sctc_ctc_loss_batch "
+                "(workspace allocation, descriptor build and pinned upload, kernel; the kernel alone: profiles/"
+                "r05_ctc_paths_kernel_stats.csv), `ms_wall` the Python entry ctc_loss_batch with its 4096 label arrays "
+                "(rounds 1-4 reported that one: 11.4 ms with the three-kernel path).  The float64 recursion is "
+                "latency/issue-bound, not HBM-bound (DESIGN.md 4.3)" % (T, U)}
 
 
 def f32_split_bf16x3(out, torch, cfg, labels, feats, net32):

@@ -101,7 +101,12 @@ typedef struct sctc_ctc_batch {
     const int32_t* rowbase_dev;/* device [max T] or NULL */
 } sctc_ctc_batch;
 
-/* bytes of device workspace sctc_ctc_loss_batch needs for this batch */
+/* bytes of device workspace sctc_ctc_loss_batch needs for this batch (0: the batch is rejected, sctc_last_error()).
+ * No bound on the label length or the alphabet (round 5; ctc_fast.pyx:22-32 has none): label rows of up to 256
+ * lattice states (2U+1) keep ONE packed half lattice per direction (the alpha / beta / gradient kernel of
+ * csrc/ctc_fused.hip), rows of up to 2048 states two float64 lattices of 64 K states per frame
+ * (csrc/ctc_kernels.hip), longer rows and alphabets beyond 256 symbols two float64 lattices of round_up(2U+2, 64)
+ * states per frame (csrc/ctc_generic.hip). */
 size_t sctc_ctc_workspace_bytes(const sctc_ctc_batch* batch);
 
 /* ctc_loss(params, seq, blank) of ctc_fast.pyx:13-152 for B utterances at once.

@@ -129,8 +129,12 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
         return set_error(SCTC_ERR_WORKSPACE, "ctc: workspace %zu bytes < %zu needed", ws_bytes,
                          ar.used);
 
-    CtcHostStage local;
-    CtcHostStage& st = keep ? *keep : local;
+    // no caller-owned stage (the standalone sctc_ctc_loss_batch): a per-thread stage that lives as long as the
+    // process (never destroyed: its pinned buffer and event must not be freed behind the HIP runtime's back at exit),
+    // so these uploads come from pinned memory too -- from pageable vectors the 4 MB of descriptors of a
+    // 4096-utterance batch cost 1 ms with the stream waiting
+    static thread_local CtcHostStage* tls_stage = new CtcHostStage();
+    CtcHostStage& st = keep ? *keep : *tls_stage;
     st.utts.resize(plan.B);
     st.labels.resize(n_int);
     std::vector<CtcUtt>& utts = st.utts;
@@ -163,13 +167,14 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
         lab_off += u.U;
     }
     const size_t utt_bytes = sizeof(CtcUtt) * plan.B, utt_span = align256(utt_bytes), lab_bytes = sizeof(int32_t) * n_int;
-    char* pin = keep ? static_cast<char*>(keep->pinned.acquire(utt_span + lab_bytes)) : nullptr;
+    char* pin = static_cast<char*>(st.pinned.acquire(utt_span + lab_bytes));
+    const bool staged_pinned = pin != nullptr;
     if (pin) {
         memcpy(pin, utts.data(), utt_bytes);
         memcpy(pin + utt_span, labels.data(), lab_bytes);
         SCTC_HIP_TRY(hipMemcpyAsync(d_utts, pin, utt_bytes, hipMemcpyHostToDevice, stream));
         SCTC_HIP_TRY(hipMemcpyAsync(d_labels, pin + utt_span, lab_bytes, hipMemcpyHostToDevice, stream));
-        SCTC_HIP_TRY(keep->pinned.uploaded(stream));
+        SCTC_HIP_TRY(st.pinned.uploaded(stream));
     } else {
         SCTC_HIP_TRY(hipMemcpyAsync(d_utts, utts.data(), utt_bytes, hipMemcpyHostToDevice, stream));
         SCTC_HIP_TRY(hipMemcpyAsync(d_labels, labels.data(), lab_bytes, hipMemcpyHostToDevice, stream));
@@ -195,7 +200,7 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
             fa.diag = dz ? atoi(dz) : 0;
         }
         SCTC_TRY(launch_ctc_fused<R>(fa, plan.B, plan.K, plan.store_bytes, stream));
-        if (!keep) SCTC_HIP_TRY(hipStreamSynchronize(stream));
+        if (!staged_pinned) SCTC_HIP_TRY(hipStreamSynchronize(stream));   // pageable staging must outlive the copies
         return SCTC_OK;
     }
     CtcLatticeArgs<R> la;
@@ -238,8 +243,8 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
         SCTC_TRY(launch_ctc_generic<R>(la, ga, plan.B, plan.max_T, stream));
     else
         SCTC_TRY(launch_ctc_grad<R>(ga, plan.B, plan.max_T, stream));
-    // the pageable host staging must outlive the async copies
-    if (!keep) SCTC_HIP_TRY(hipStreamSynchronize(stream));
+    // pageable host staging must outlive the async copies
+    if (!staged_pinned) SCTC_HIP_TRY(hipStreamSynchronize(stream));
     return SCTC_OK;
 }
 
