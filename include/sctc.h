@@ -102,7 +102,7 @@ typedef struct sctc_ctc_batch {
 } sctc_ctc_batch;
 
 /* bytes of device workspace sctc_ctc_loss_batch needs for this batch (0: the batch is rejected, sctc_last_error()).
- * No bound on the label length or the alphabet (round 5; ctc_fast.pyx:22-32 has none): label rows of up to 256
+ * No bound on the label length or the alphabet (round 5; ctc_fast.pyx:22-32 has none): label rows of up to 512
  * lattice states (2U+1) keep ONE packed half lattice per direction (the alpha / beta / gradient kernel of
  * csrc/ctc_fused.hip), rows of up to 2048 states two float64 lattices of 64 K states per frame
  * (csrc/ctc_kernels.hip), longer rows and alphabets beyond 256 symbols two float64 lattices of round_up(2U+2, 64)

@@ -62,14 +62,24 @@ int ctc_make_plan(int B, int A, int blank, int dtype, const int32_t* T_b, const 
     plan->max_T = max_T;
     plan->frames = frames;
     plan->n_labels = n_labels;
-    // Rows of up to 256 states: both recursions and the gradient in ONE kernel that keeps one packed half lattice
+    // Rows of up to 512 states: both recursions and the gradient in ONE kernel that keeps one packed half lattice
     // per direction (ctc_fused.hip).  SCTC_CTC_FUSED=0 runs the three-kernel path (A/B, tests); the lazy rescaling
     // schedule exists there only.  Float32 probabilities keep their rows in the 32-bit format of ctc_fused.hip
     // unless SCTC_CTC_STORE=64.
     {
         const char* fz = getenv("SCTC_CTC_FUSED");
         const char* sb = getenv("SCTC_CTC_STORE");
-        plan->fused = !plan->generic && W == 1 && K <= 4 && !plan->lazy && (fz ? atoi(fz) != 0 : true);
+        // the fused kernel's own shape: one wave per direction with 2 / 4 / 8 states per lane (rows of up to 128 / 256 /
+        // 512 states: cfg-4's 401 included)
+        const int fk = max_L <= 128 ? 2 : (max_L <= 256 ? 4 : (max_L <= 512 ? 8 : 0));
+        plan->fused = !plan->generic && fk > 0 && A <= 256 && !plan->lazy && (fz ? atoi(fz) != 0 : true);
+        if (plan->fused) {
+            K = fk;
+            W = 1;
+            plan->K = K;
+            plan->W = 1;
+            plan->lp = 64 * K;
+        }
         plan->store_bytes = (dtype == SCTC_F32 && !(sb && atoi(sb) == 64)) ? 4 : 8;
     }
     const size_t head = align256(sizeof(CtcUtt) * B) + align256(sizeof(int32_t) * (2 * n_labels + (int64_t)B * (A + 1)));

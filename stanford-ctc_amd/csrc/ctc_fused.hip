@@ -1,6 +1,6 @@
 // CTC forward-backward with the gradient formed INSIDE the two recursions ("meet in the middle"):
-// the device counterpart of ctc_fast/ctc-loss/ctc_fast.pyx:13-152 for label rows of up to 256
-// lattice states (2U+1 <= 256: every shape of BASELINE configs[0..3]).
+// the device counterpart of ctc_fast/ctc-loss/ctc_fast.pyx:13-152 for label rows of up to 512
+// lattice states (2U+1 <= 512: every shape of BASELINE configs[0..3]; 2, 4 or 8 states per lane).
 //
 // One workgroup = one utterance = two waves: wave 0 runs the scaled alpha recursion
 // (ctc_fast.pyx:42-76), wave 1 the beta recursion (:79-114) as an alpha pass on the reversed
@@ -42,6 +42,7 @@
 // per label state and block of frames, off the recursion's dependency chain.  The sums themselves
 // are taken as fixed trees (bit-reproducible run to run; the reference adds in ascending state
 // order: differences are in the last bits, the float64 golden vectors hold at 1e-11 / 1e-9).
+#include <mutex>
 #include <type_traits>
 
 #ifndef SCTC_FUSED_PF2
@@ -92,7 +93,7 @@ template <typename RI, typename ST, int K, int NA, bool HELP>
 __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
 {
     using R = double;
-    static_assert(K == 2 || K == 4, "one wave per direction: 2 or 4 states per lane");
+    static_assert(K == 2 || K == 4 || K == 8, "one wave per direction: 2, 4 or 8 states per lane (rows of up to 512 states)");
     constexpr int KH = K / 2;
     // Frames per block: the probabilities (and, phase 1, the other direction's rows) of a block are
     // prefetched a block ahead, a block's rows are stored / its gradient rows finished behind its last
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
     // does not feed the recursion is scheduled into the gaps of its dependency chain.
     // (two-wave form: 4 -- 190 instead of 296 registers, two waves per SIMD instead of one: 4.1 -> 3.5 ms at 4096
     // utterances; it is the form of the batches that fill the device)
-    constexpr int PF = HELP ? 8 : SCTC_FUSED_PF2;
+    constexpr int PF = HELP ? (K == 8 ? 4 : 8) : SCTC_FUSED_PF2;
     constexpr int NI = NA == 1 ? 8 : 4;     // list entries of a label summed unconditionally
     constexpr int NI2 = NA == 1 ? 16 : NI;  // list entries kept in registers (those beyond NI: summed when some list is that long)
     constexpr int NPOS = 64 * KH;           // label positions of one direction; slot NPOS holds 0.0
@@ -123,9 +124,17 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
     __shared__ __attribute__((aligned(16))) double lab_s[2][NH][FS][LSTR];   // alpha*beta of the label states, per frame
     // the transposed sums of a finish: their own scratch without helpers; with helpers the ring half the helper has
     // just read into registers (released once the sums are read back)
-    __shared__ __attribute__((aligned(16))) double red_s[HELP ? 1 : 2][HELP ? 1 : 2 * FS][HELP ? 2 : RSTR];
-    __shared__ __attribute__((aligned(16))) double ring_s[HELP ? 2 : 1][2][HB][HELP ? 64 * K : 2];
-    static_assert(!HELP || 2 * HB * RSTR <= HB * 64 * K, "the sums of a hand-over fit its ring half");
+    // (8 states per lane: the ring is dynamic LDS and the helpers have room for sums of their own: their rows are
+    // then multiplied one at a time instead of all HB being held in registers first)
+    __shared__ __attribute__((aligned(16))) double red_s[(HELP && K < 8) ? 1 : (HELP ? 4 : 2)][(HELP && K < 8) ? 1 : 2 * FS][(HELP && K < 8) ? 2 : RSTR];
+    // the ring: [direction][half][HB frames][64 K states]; 8 states per lane (rows of up to 512 states, round 5:
+    // cfg-4's 401) make it 64 KiB, which only fits as dynamic LDS beside the rest
+    constexpr bool DYN_RING = HELP && K == 8;
+    extern __shared__ __attribute__((aligned(16))) double ring_dyn[];
+    __shared__ __attribute__((aligned(16))) double ring_static[(HELP && !DYN_RING) ? 2 * 2 * HB * 64 * K : 2];
+    double* const ring_base = DYN_RING ? ring_dyn : ring_static;
+    auto ring_half = [&](int d, int half) -> double* { return ring_base + (size_t)((d * 2 + half) * HB) * 64 * K; };
+    static_assert(!HELP || K == 8 || 2 * HB * RSTR <= HB * 64 * K, "the sums of a hand-over fit its ring half");
     __shared__ int32_t prod_s[2], cons_s[2][2];   // hand-overs published per direction / consumed per helper
     __shared__ int32_t ord_pos[2][NPOS];
     __shared__ int32_t sh_skip[2];
@@ -299,6 +308,7 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
         }
     };
     auto local_sum = [&](const R (&n)[K]) -> R {
+        if constexpr (K == 8) return ((n[0] + n[1]) + (n[2] + n[3])) + ((n[4] + n[5]) + (n[6] + n[7]));
         if constexpr (K == 2) return n[0] + n[1];
         else return (n[0] + n[1]) + (n[2] + n[3]);
     };
@@ -391,7 +401,10 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
         }
         zl = z;
         eb = e;
-        if constexpr (KH == 2) {
+        if constexpr (KH == 4) {
+            *reinterpret_cast<double2*>(&lab_s[dir][par][slot][4 * gl]) = make_double2(ab[1], ab[3]);
+            *reinterpret_cast<double2*>(&lab_s[dir][par][slot][4 * gl + 2]) = make_double2(ab[5], ab[7]);
+        } else if constexpr (KH == 2) {
             *reinterpret_cast<double2*>(&lab_s[dir][par][slot][2 * gl]) = make_double2(ab[1], ab[3]);
         } else {
             lab_s[dir][par][slot][gl] = ab[1];
@@ -665,7 +678,7 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
             for (int hb = 0; hb < PF / HB; ++hb) {
                 const int h = blk * (PF / HB) + hb;
                 if (!(p.diag & 8)) wait_for(&cons_s[dir][h & 1], h >> 1);   // hand-over h - 2 (same ring half) has been consumed
-                double2* slot = reinterpret_cast<double2*>(&ring_s[dir][h & 1][0][0]);
+                double2* slot = reinterpret_cast<double2*>(ring_half(dir, h & 1));
                 if (fast) {
 #pragma unroll
                     for (int i = 0; i < HB; ++i) {
@@ -708,7 +721,7 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
             load_other(t_begin + par * HB + i, ocur[i]);
         }
         int rb_nxt = block_rows(t_begin + (par + 2) * HB);
-        double* half = &ring_s[dir][par][0][0];
+        double* half = ring_half(dir, par);
         for (int h = par; h < nh; h += 2) {
             const int tb = t_begin + h * HB;
             RI ynxt[HB][NA];
@@ -736,6 +749,26 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
             wait_for(&prod_s[dir], h + 1);
             R zl[HB], eb[HB];
             const double2* slot = reinterpret_cast<const double2*>(half);
+            auto release = [&]() {
+                __hip_atomic_store(&cons_s[dir][par], (h >> 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");
+            };
+            if constexpr (DYN_RING) {
+#pragma unroll
+                for (int i = 0; i < HB; ++i) {
+                    R av[K];
+#pragma unroll
+                    for (int j = 0; j < K; j += 2) {
+                        const double2 v = slot[(i * 64 * K + K * lane + j) / 2];
+                        av[j] = v.x;
+                        av[j + 1] = v.y;
+                    }
+                    products(i, av, ocur[i], rbv[i], rlv[i], zl[i], eb[i]);
+                }
+                lds_order();
+                release();       // the rows have been read; the sums go to this helper's own scratch
+                finish_block(std::integral_constant<int, HB>(), &red_s[2 * dir + par][0][0], [] {}, tb, t_end, ycur, rb_cur, zl, eb);
+            } else {
             R av[HB][K];
 #pragma unroll
             for (int i = 0; i < HB; ++i)
@@ -751,12 +784,9 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
                 if (!(p.diag & 4)) products(i, av[i], ocur[i], rbv[i], rlv[i], zl[i], eb[i]);
                 else { zl[i] = av[i][0]; eb[i] = av[i][1]; }
             }
-            auto release = [&]() {
-                __hip_atomic_store(&cons_s[dir][par], (h >> 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                asm volatile("" ::: "memory");
-            };
             if (!(p.diag & 2)) finish_block(std::integral_constant<int, HB>(), half, release, tb, t_end, ycur, rb_cur, zl, eb);
             else release();
+            }
 #pragma unroll
             for (int i = 0; i < HB; ++i) {
 #pragma unroll
@@ -813,7 +843,7 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
             rl[jj] = recip_or_zero(valid_lab[jj] ? g : (R)0);
         }
         products(0, a, ob, recip_or_zero(bcast(yc[0], blank)), rl, zl[0], eb[0]);
-        finish_block(std::integral_constant<int, FS>(), HELP ? &ring_s[0][0][0][0] : &red_s[0][0][0], [] {}, 0, 1, yc, rows, zl, eb);
+        finish_block(std::integral_constant<int, FS>(), (HELP && K < 8) ? ring_half(0, 0) : &red_s[0][0][0], [] {}, 0, 1, yc, rows, zl, eb);
     }
     const int t1_end = (p.diag & 1) ? 0 : T;
     if constexpr (HELP) {
@@ -850,15 +880,37 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
 
 // ---------------------------------------------------------------- launcher
 
+template <typename RI, typename ST, int K, int NA, bool HELP>
+static int launch_fused_one(const CtcFusedArgs<RI>& a, int B, hipStream_t stream)
+{
+    dim3 grid(B), block(HELP ? 384 : 128);
+    // 8 states per lane with helper waves: the 64 KiB ring is dynamic LDS (static + dynamic > 64 KiB needs the attribute)
+    const size_t dyn = (HELP && K == 8) ? sizeof(double) * 2 * 2 * 4 * 64 * K : 0;
+    if (dyn) {
+        static std::once_flag once;     // one per instantiation
+        static hipError_t attr = hipSuccess;
+        std::call_once(once, [&] {
+            attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fused_kernel<RI, ST, K, NA, HELP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        });
+        SCTC_HIP_TRY(attr);
+    }
+    hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, NA, HELP>), grid, block, dyn, stream, a);
+    SCTC_HIP_TRY(hipGetLastError());
+    return SCTC_OK;
+}
+
 template <typename RI, typename ST, int K, bool HELP>
 static int launch_fused_kh(const CtcFusedArgs<RI>& a, int B, int NA, hipStream_t stream)
 {
-    dim3 grid(B), block(HELP ? 384 : 128);
-    if (NA == 1) hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, 1, HELP>), grid, block, 0, stream, a);
-    else if (NA == 2) hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, 2, HELP>), grid, block, 0, stream, a);
-    else if constexpr (!HELP) hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, 4, false>), grid, block, 0, stream, a);
-    SCTC_HIP_TRY(hipGetLastError());
-    return SCTC_OK;
+    if constexpr (!(HELP && K == 8 && sizeof(ST) == 8)) {
+        if (NA == 1) return launch_fused_one<RI, ST, K, 1, HELP>(a, B, stream);
+    }
+    if constexpr (!(HELP && K == 8)) {
+        if (NA == 2) return launch_fused_one<RI, ST, K, 2, HELP>(a, B, stream);
+    }
+    if constexpr (!HELP) return launch_fused_one<RI, ST, K, 4, false>(a, B, stream);
+    return set_error(SCTC_ERR_ARG, "ctc: no helper form for %d probability registers per frame", NA);
 }
 
 template <typename RI, typename ST, int K>
@@ -872,7 +924,9 @@ static int launch_fused_k(const CtcFusedArgs<RI>& a, int B, int NA, hipStream_t 
     const char* hz = getenv("SCTC_CTC_HELPER");
     const char* mz = getenv("SCTC_CTC_HELPER_MAX_B");
     const int max_b = mz ? atoi(mz) : 256;
-    const bool help = NA <= 2 && (hz ? atoi(hz) != 0 : B <= max_b);
+    // (8 states per lane: helpers only for alphabets of up to 64 symbols -- the register budget again)
+    // and for the 32-bit row store -- the register budget again)
+    const bool help = (K == 8 ? (NA == 1 && sizeof(ST) == 4) : NA <= 2) && (hz ? atoi(hz) != 0 : B <= max_b);
     if (help) return launch_fused_kh<RI, ST, K, true>(a, B, NA, stream);
     return launch_fused_kh<RI, ST, K, false>(a, B, NA, stream);
 }
@@ -885,11 +939,13 @@ int launch_ctc_fused(const CtcFusedArgs<RI>& a, int B, int K, int store_bytes, h
         if (store_bytes == 4) {
             if (K == 2) return launch_fused_k<RI, uint32_t, 2>(a, B, NA, stream);
             if (K == 4) return launch_fused_k<RI, uint32_t, 4>(a, B, NA, stream);
+            if (K == 8) return launch_fused_k<RI, uint32_t, 8>(a, B, NA, stream);
         }
     }
     if (store_bytes == 8) {
         if (K == 2) return launch_fused_k<RI, double, 2>(a, B, NA, stream);
         if (K == 4) return launch_fused_k<RI, double, 4>(a, B, NA, stream);
+        if (K == 8) return launch_fused_k<RI, double, 8>(a, B, NA, stream);
     }
     return set_error(SCTC_ERR_ARG, "ctc: no fused kernel for K=%d, %d-byte rows", K, store_bytes);
 }

@@ -54,7 +54,7 @@ struct CtcGradArgs {
     int32_t lazy;   // lattices were produced with the every-4th-frame rescaling
 };
 
-// ctc_fused.hip: both recursions and the gradient in one kernel (label rows of up to 256 states).
+// ctc_fused.hip: both recursions and the gradient in one kernel (label rows of up to 512 states).
 // `store` holds, per utterance, T rows of round_up(2U+1, K) states (alpha's first T/2 frames, then
 // beta's first T - T/2) behind a K-element pad, as float64 or in the 32-bit format of ctc_fused.hip;
 // CtcUtt::lat_off counts elements of that type.
@@ -100,7 +100,7 @@ struct CtcPlan {
     int B = 0, A = 0, blank = 0, K = 0, W = 1, lp = 0, max_T = 0;   // lp = 64*W*K
     int lazy = 0;           // SCTC_CTC_LAZY=1: float32 probabilities rescale every 4th frame only
     int generic = 0;        // ctc_generic.hip: 2U+1 > 2048 or A > 256 (or SCTC_CTC_GENERIC=1); lp = round_up(2U+2, 64)
-    int fused = 0;          // ctc_fused_kernel (one wave per direction, rows of <= 256 states); lat_elems then counts
+    int fused = 0;          // ctc_fused_kernel (one wave per direction, rows of <= 512 states); lat_elems then counts
                             // the elements of its ONE packed row store, store_bytes (4 / 8) each
     int store_bytes = 8;
     int64_t frames = 0;

@@ -1,6 +1,6 @@
 """GPU parity of the three CTC code paths behind `ctc_fast.ctc_loss` / `ctc_loss_batch` (round 5):
 
-  fused     ctc_fused.hip      both recursions + the gradient in one kernel, rows of <= 256 states (default there);
+  fused     ctc_fused.hip      both recursions + the gradient in one kernel, rows of <= 512 states (default there);
                                "fused2w" = the same without helper waves (SCTC_CTC_HELPER=0)
   lattice   ctc_kernels.hip    ctc_lattice + ctc_grad, rows of <= 2048 states (SCTC_CTC_FUSED=0 forces it)
   generic   ctc_generic.hip    any label length, any alphabet (SCTC_CTC_GENERIC=1 forces it)
@@ -83,6 +83,8 @@ SHAPES = [  # (A, T, U): one and two states per lane pair, every T parity around
     (4, 1, 1), (4, 2, 1), (5, 3, 1), (5, 3, 3), (6, 4, 2), (7, 7, 3), (7, 8, 4), (9, 9, 4), (33, 15, 6), (33, 16, 7),
     (33, 17, 8), (33, 31, 15), (28, 100, 30), (33, 333, 63), (33, 200, 64), (62, 300, 100), (33, 260, 127),
     (100, 129, 127), (200, 77, 20), (130, 64, 31), (3, 240, 60), (2, 40, 9),
+    # 8 states per lane (rows of 257..512 states; cfg-4: T=2000, U=200 is 401): the 256 / 257 and 511 / 513 edges
+    (33, 300, 128), (33, 520, 200), (62, 400, 255), (70, 300, 180), (150, 280, 129), (33, 700, 256),
 ]
 
 
@@ -173,7 +175,7 @@ def test_fused_f32_row_store(mods):
     cf, octc, torch = mods
     rs = np.random.RandomState(3)
     cases = [(33, 1000, 100, 1.0), (33, 1000, 20, 1.0), (33, 2000, 100, 1.0), (33, 1000, 100, 4.0), (62, 300, 120, 1.0),
-             (28, 200, 30, 6.0), (33, 999, 127, 1.0), (5, 601, 50, 1.0)]
+             (28, 200, 30, 6.0), (33, 999, 127, 1.0), (5, 601, 50, 1.0), (33, 2000, 200, 1.0), (33, 1203, 255, 1.0)]
     probs, seqs = [], []
     for A, T, U, peaked in cases:
         y, seq = _case(rs, A, T, U, peaked=peaked)
@@ -207,7 +209,7 @@ def test_fused_ragged_batch_and_long_lists(mods):
     for A, dt in ((33, np.float64), (3, np.float32), (70, np.float32), (150, np.float64)):
         probs, seqs = [], []
         for b in range(37):
-            U = int(rs.randint(1, 128))
+            U = int(rs.randint(1, 256 if A in (33, 70) else 128))
             T = int(rs.randint(max(1, U // 2), 3 * U + 2))
             y, seq = _case(rs, A, T, U, with_blank_labels=(b % 5 == 0), all_same=(b % 11 == 3))
             probs.append(np.asfortranarray(y.astype(dt)))

@@ -20,7 +20,7 @@ import torch  # noqa: E402
 import ctc_fast  # noqa: E402
 
 SHAPES = {"cfg3": (32, 1000, 100, 33), "sat": (4096, 1000, 100, 33), "cfg2": (256, 300, 60, 62),
-          "cfg5": (8, 8000, 800, 33), "sat1k": (1024, 1000, 100, 33)}
+          "cfg5": (8, 8000, 800, 33), "sat1k": (1024, 1000, 100, 33), "cfg4": (32, 2000, 200, 33), "sat4": (2048, 2000, 200, 33)}
 PATHS = {"fused": {}, "fused64": {"SCTC_CTC_STORE": "64"}, "fused2w": {"SCTC_CTC_HELPER": "0"},
          "lattice": {"SCTC_CTC_FUSED": "0"}}
 
