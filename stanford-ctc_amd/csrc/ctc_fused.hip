@@ -326,14 +326,16 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
     constexpr int NO_BAD = 0x7fffffff;
     int first_bad = NO_BAD;
     int skip = 0;
-    // llForward = sum_t log c_t (ctc_fast.pyx:47,76) = -log of the product of the applied factors r_t = 1/c_t:
-    // the product is carried as mantissa x 2^exponent (three operations per frame, beside the recursion's
-    // chain) and its logarithm taken once; frames from the first zero band sum on do not count (the
-    // reference's exception leaves llForward as it was, :147-149)
+    // llForward = sum_t log c_t (ctc_fast.pyx:47,76) = log of the product of the band sums c_t: the product is carried
+    // as mantissa x 2^exponent (three operations per frame, beside the recursion's chain) and its logarithm taken
+    // once; frames from the first zero band sum on do not count (the reference's exception leaves llForward as it
+    // was, :147-149).  The product of the c_t themselves, not of the applied factors 1/c_t: for T = 1 the cost is then
+    // the logarithm of the very double the reference takes it of (a cost of 1e-8 -- one frame, c = 1 - 1e-8 -- would
+    // otherwise carry the reciprocal's rounding: 2e-8 relative, found by the fuzz test).
     R ll_m = (R)1;
     int ll_e = 0;
-    auto ll_account = [&](R r) {
-        const R f = first_bad == NO_BAD ? r : (R)1;
+    auto ll_account = [&](R c) {
+        const R f = first_bad == NO_BAD ? c : (R)1;
         ll_m *= f;
         ll_e += __builtin_amdgcn_frexp_exp(ll_m);
         ll_m = __builtin_amdgcn_frexp_mant(ll_m);
@@ -381,7 +383,8 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) a[j] = n[j] * r;
-        ll_account(r);
+        if constexpr (FAST) ll_account(c);
+        else ll_account(empty_band ? (R)1 : c);
     };
     // phase 1, inside the frame: alpha*beta of my states against the other direction's stored row;
     // label products to the frame's LDS slot, the lane's share of absum[t] (zl) and of the blank sum (eb)
@@ -815,7 +818,7 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
             const R r = recip(c);
             a[0] *= r;
             a[1] *= r;
-            ll_account(r);
+            ll_account(c);
         }
         if (Tst > 0 && store_lane) {
             BlkA blk;
@@ -854,8 +857,13 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
     }
 
     if (wave == 0 && lane == 0) {
-        // -llForward (ctc_fast.pyx:149,152); math.log(0.0) for the empty band
-        double cost = log(ll_m) + (double)ll_e * 0.693147180559945309417232121458;
+        // -llForward (ctc_fast.pyx:149,152); math.log(0.0) for the empty band.  Mantissa in [sqrt(1/2), sqrt(2)): a
+        // product near 1 has exponent 0 and its logarithm no cancellation against exponent x ln 2
+        if (ll_m < 0.70710678118654752440) {
+            ll_m *= 2.0;
+            ll_e -= 1;
+        }
+        double cost = -(log(ll_m) + (double)ll_e * 0.693147180559945309417232121458);
         if (empty_band && !skip) cost = INFINITY;
         sh_cost = cost;
     }

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(GEN_NT) void ctc_lattice_generic_kernel(CtcLatticeA
             sc[s] = v;
             lat[s] = v * rprev;
         }
-        if (tid == 0) lat[LP - 1] = rprev;
+        if (tid == 0) lat[LP - 1] = skip ? 1.0 : c;   // the band sum itself: llForward takes its logarithm (ctc_kernels.hip)
     }
     __syncthreads();
     for (int tau = 1; tau < T && !skip; ++tau) {
@@ -145,14 +145,14 @@ __global__ __launch_bounds__(GEN_NT) void ctc_lattice_generic_kernel(CtcLatticeA
         }
         double* row = lat + (int64_t)tau * LP;
         for (int s = tid; s < L; s += GEN_NT) row[s] = ld_l2(cur + s) * r;
-        if (tid == 0) row[LP - 1] = r;
+        if (tid == 0) row[LP - 1] = empty_band ? 1.0 : c;
         rprev = r;
     }
-    // llForward = sum_t log c_t = - sum of log over the stored factors (ctc_lattice_kernel's order)
+    // llForward = sum_t log c_t over the stored band sums (ctc_lattice_kernel's order)
     __syncthreads();
     if (tid < 64) {
         double ll = 0.0;
-        for (int tau = tid; tau < n_rows; tau += 64) ll -= log(ld_l2(lat + (int64_t)tau * LP + (LP - 1)));
+        for (int tau = tid; tau < n_rows; tau += 64) ll += log(ld_l2(lat + (int64_t)tau * LP + (LP - 1)));
         double total = wave_sum(ll);
         if (tid == 0) {
             if (empty_band && !skip) total = -INFINITY;

@@ -377,6 +377,9 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
     int skip = 0;
     int n_rows = T;    // rows stored with their factor: all of them, or those before the frame that skipped
     R rprev = (R)1;    // factor applied to the previous frame's row (uniform)
+    R cfac = (R)1;     // the band sum that factor is the reciprocal of (1 where the row was not rescaled): stored beside
+                       // the row; llForward takes the logarithm of the c_t themselves like the reference (a cost of 1e-8
+                       // -- one frame, c = 1 - 1e-8 -- would otherwise carry the reciprocal's rounding, 2e-8 relative)
     // T < U: the band [start,end) is empty at every frame t >= 1 (L >= 2T+2 does not depend
     // on t): the reference divides nothing, takes log(0) = -inf and returns cost +inf with
     // skip False (ctc_fast.pyx:70-76 on an empty range)
@@ -399,8 +402,9 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
             a[0] *= r;
             a[1] *= r;
             rprev = r;
+            cfac = c;
         }
-        store_row(0, a, rprev);
+        store_row(0, a, cfac);
     }
 
     if (!skip && empty_band) {
@@ -466,13 +470,15 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
 #pragma unroll
                             for (int j = 0; j < K; ++j) a[j] = n[j] * r;
                             rprev = r;
+                            cfac = c;
                         } else {
                             publish(n[K - 1], tau);
                             rprev = (R)1;
+                            cfac = (R)1;
 #pragma unroll
                             for (int j = 0; j < K; ++j) a[j] = n[j];
                         }
-                        store_row(tau, a, rprev);
+                        store_row(tau, a, cfac);
                     }
                 }
             } else {
@@ -513,13 +519,15 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
 #pragma unroll
                         for (int j = 0; j < K; ++j) a[j] = n[j] * r;
                         rprev = r;
+                        cfac = c;
                     } else {
                         publish(n[K - 1], tau);
                         rprev = (R)1;
+                        cfac = (R)1;
 #pragma unroll
                         for (int j = 0; j < K; ++j) a[j] = n[j];
                     }
-                    store_row(tau, a, rprev);
+                    store_row(tau, a, cfac);
                 }
             }
             }
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
                 for (int q = 0; q < NA; ++q) ycur[i][q] = ynxt[i][q];
         }
     }
-    // llForward = sum_t log c_t (ctc_fast.pyx:47,76) = - sum over the stored factors.  The wave that
+    // llForward = sum_t log c_t (ctc_fast.pyx:47,76) = sum over the logarithms of the stored band sums.  The wave that
     // stored them reads them back (its own stores, drained first; the lines were never cached):
     // lane l takes frames l, l+64, ... in ascending order -- the order the in-register scheme this
     // replaces summed them in, so llForward is bit-identical to it.
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         double ll = 0.0;   // per-lane partial of llForward (float64 like the reference)
         const R* fac = lat + (LP - 1);
-        for (int tau = lane; tau < n_rows; tau += 64) ll -= log((double)fac[(int64_t)tau * LP]);
+        for (int tau = lane; tau < n_rows; tau += 64) ll += log((double)fac[(int64_t)tau * LP]);
         double total = wave_sum(ll);
         if (lane == 0) {
             if (empty_band && !skip) total = -INFINITY;  // math.log(0.0)
