@@ -503,6 +503,7 @@ def main():
             ctc_saturation(out, torch, A, T, U)
             del net, feats, dev_bufs
             torch.cuda.empty_cache()
+            cfg4_share(out, torch)
             cfg5_fp16(out, torch)
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
@@ -836,6 +837,48 @@ def cfg5_fp16(out, torch):
                                     "operand_dtype fp16 (float16 forward / bfloat16 backward operands, fp32 "
                                     "accumulate, float64 CTC lattices), HBM-resident features",
                         "dtype": "f16 operands / f32 accumulate", **res}
+
+
+def cfg4_share(out, torch):
+    """BASELINE configs[3] (SWBD shape, minibatch 256 over 8 GPUs): ONE GPU's share -- 32 utterances of T=2000, A=33,
+    5x1824 (temporalLayer 3, inputDim 615), U=200, fp32 -- as a side field, never `value`.  It is the N = 1 leg of the
+    weak-scaling run `bench.py --gpus 8` would do on that configuration; its 401-state label rows take the fused CTC
+    kernel with 8 states per lane."""
+    from nnets import brnnet
+    import _sctc
+    D, A, H, NL, TL, T, U, B = 615, 33, 1824, 5, 3, 2000, 200, 32
+    np.random.seed(0)
+    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B, gemm="f32")
+    net.initParams()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4)
+    feats = torch.randn(B * T, D, device="cuda", generator=g)
+    rs = np.random.RandomState(4)
+    labels = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
+    Ts = [T] * B
+    net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    L = _sctc.lib()
+    L.sctc_brnn_set_profiling(net._h, 1)
+    net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+    arr = (ctypes.c_float * len(PHASES))()
+    L.sctc_brnn_phase_ms(net._h, arr)
+    L.sctc_brnn_set_profiling(net._h, 0)
+    ph = dict(zip(PHASES, [float(v) for v in arr]))
+    out["cfg4_share"] = {"workload": "cfg-4, one GPU's share of the 8-GPU minibatch 256: 32 utterances of T=2000 A=33 5x1824 BRNN "
+                                     "(temporalLayer 3, inputDim 615) U=200, fp32, HBM-resident features",
+                         "value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "phase_ms": ph,
+                         "ctc_ms": ph["ctc"], "us_per_recurrent_step": (ph["fwd_rec"] + ph["bwd_rec"]) * 1e3 / (2 * (T - 1)),
+                         "note": "what each of 8 ranks would do per step before the RCCL all-reduce of the 20.9 M-parameter gradient; "
+                                 "no 8-GPU node was available to any round (DESIGN.md 7)"}
+    del net, feats
+    torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":

@@ -306,3 +306,27 @@ def test_long_label_row_through_the_network_and_the_trainer_check(mods):
     import _sctc
     with pytest.raises((_sctc.SctcError, ValueError)):
         net.costAndGrad(rs.randn(D, 2000), rs.randint(1, A, size=1100).astype(np.int32))
+
+
+@pytest.mark.parametrize("which", ["fused", "fused2w", "lattice", "generic"])
+def test_tiny_cost_is_the_log_of_the_band_sum_itself(mods, which):
+    """one frame whose blank + label probabilities sum to 1 - 1e-8: the cost is 1e-8 and every path must return the
+    logarithm of that very sum (rounds 1-4 took the logarithm of the applied reciprocal: 2e-8 relative error, found
+    by the round-5 fuzz soak, seed 5 case 131); a longer utterance of such frames likewise"""
+    cf, octc, _ = mods
+    with path(which):
+        for T, U in ((1, 1), (1, 20), (2, 1), (9, 2)):
+            y = np.zeros((3, T))
+            y[0], y[1], y[2] = 0.25, 0.75 - 1e-8, 1e-8
+            seq = np.full(U, 1, dtype=np.int32)
+            if U == 2:
+                seq[1] = 2
+                y[2], y[1] = 0.5, 0.25 - 1e-8          # label 2 must be reachable
+            y = np.asfortranarray(y)
+            with np.errstate(all="ignore"):
+                c_ref, g_ref, s_ref = octc.ctc_loss(y, seq)
+                cost, grad, skip = cf.ctc_loss(y, seq)
+            assert bool(skip) == bool(s_ref)
+            if not s_ref and np.isfinite(c_ref):
+                assert abs(cost - c_ref) <= 1e-10 * abs(c_ref) + 1e-300, (which, T, U, cost, c_ref)
+                assert np.abs(grad - g_ref).max() < 1e-9
