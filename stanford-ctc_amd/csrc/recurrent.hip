@@ -1993,6 +1993,29 @@ static int launch_recurrent_one(const RecArgs& a, const LaunchCtx& cx)
             if (done) return SCTC_OK;
         }
     }
+    // 6..16 utterances are ONE 16-utterance chain: the flag kernel of the 17..32 case with a single chain per direction
+    // (one workgroup per CU instead of two).  Round 5 ("7.16 us at B = 16 is suspicious" -- it was): at
+    // H = 1824 it needs 4.66 / 4.57 / 4.80 / 4.97 us per step at 6 / 8 / 12 / 16 utterances where the sentinel / MFMA
+    // kernel below needs 4.92 / 5.00 / 6.09 / 7.16 (H = 2048: 5.45 against 7.31 at 16), with bit-identical costs and
+    // gradients (tools/rec_mid_bench.py): it is the default for fp32 operands; variant 42 keeps the sentinel kernel.
+    if (!a.prec16 && a.B > 5 && a.B <= 16 && a.variant != 1 && a.variant != 42 && 2 * nwg <= cx.cus) {
+        RecKernel qk = nullptr;
+        int ncq = 0, nreg = 0;
+        switch (nwg) {
+            case 32:  qk = brnn_recurrent_q_kernel<8, 0>;   ncq = 8;  nreg = 0;  break;  // H = 512
+            case 64:  qk = brnn_recurrent_q_kernel<16, 0>;  ncq = 16; nreg = 0;  break;  // H = 1024
+            case 114: qk = brnn_recurrent_q_kernel<29, 10>; ncq = 29; nreg = 10; break;  // H = 1824
+            case 128: qk = brnn_recurrent_q_kernel<32, 13>; ncq = 32; nreg = 13; break;  // H = 2048
+            default: break;
+        }
+        if (qk) {
+            RecArgs b = a;
+            b.variant = 2;      // linear block -> (chain, producer) map: chain = direction, tile 0 only
+            const size_t smem = sizeof(float4) * ((size_t)4 * (ncq - nreg) * 64 + 3 * 64);
+            SCTC_TRY(launch_persistent(qk, 2 * nwg, smem, 2, 0, b, cx, &done));
+            if (done) return SCTC_OK;
+        }
+    }
     if (a.B > 5 && a.B <= 16 && a.variant != 1) {
         RecKernel mk = nullptr;
         switch ((nwg + 3) / 4) {

@@ -470,10 +470,13 @@ def test_recurrent_small_batch_kernel_layer_sizes(mods, monkeypatch, H):
     assert costs[1] == pytest.approx(c_ref, rel=1e-4)
 
 
-@pytest.mark.parametrize("H,B", [(512, 6), (512, 16), (1824, 9), (2048, 12), (1024, 7)])
-def test_recurrent_mid_batch_kernel(mods, monkeypatch, H, B):
-    """6..16 utterances run the sentinel-exchange MFMA kernel (brnn_recurrent_m_kernel): ragged
-    minibatch against the flag-based kernel (SCTC_REC_VARIANT=1) and, at H=512, the oracle"""
+@pytest.mark.parametrize("variant", ["0", "42"])
+@pytest.mark.parametrize("H,B", [(512, 6), (512, 16), (1824, 9), (2048, 12), (1024, 7), (1824, 16)])
+def test_recurrent_mid_batch_kernel(mods, monkeypatch, H, B, variant):
+    """6..16 utterances: since round 5 the flag kernel with ONE chain per direction (brnn_recurrent_q_kernel on half
+    its grid; variant 0), before that the sentinel-exchange MFMA kernel (brnn_recurrent_m_kernel; variant 42): ragged
+    minibatch against the one-workgroup-per-CU flag kernel (SCTC_REC_VARIANT=1) and, at H=512, the oracle; the two
+    agree bit for bit"""
     _, brnnet, obrnn, _ = mods
     rs = np.random.RandomState(31 * H + B)
     D, A, NL, TL = 32, 33, 2, 1
@@ -483,8 +486,10 @@ def test_recurrent_mid_batch_kernel(mods, monkeypatch, H, B):
     params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
     datas = [rs.randn(D, T) for T in Ts]
     labs = [rs.randint(1, A, size=max(1, T // 8)).astype(np.int32) for T in Ts]
+    monkeypatch.setenv("SCTC_REC_VARIANT", variant)
     net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
     costs, _, skips = net.costAndGradBatch(datas, labs)
+    assert net.recurrentPath()[:2] == (1, 1)
     g_m = _all_grads(net, NL)
     net.costAndGradBatch(datas, labs)
     for a, b in zip(g_m, _all_grads(net, NL)):
@@ -501,6 +506,13 @@ def test_recurrent_mid_batch_kernel(mods, monkeypatch, H, B):
     np.testing.assert_allclose(costs[~skips], costs1[~skips], rtol=1e-5)
     for a, b in zip(g_m, _all_grads(net1, NL)):
         assert rel(a, b) < 1e-4
+    if variant == "0":
+        monkeypatch.setenv("SCTC_REC_VARIANT", "42")
+        net2 = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
+        costs2, _, _ = net2.costAndGradBatch(datas, labs)
+        np.testing.assert_array_equal(costs, costs2)
+        for a, b in zip(g_m, _all_grads(net2, NL)):
+            np.testing.assert_array_equal(a, b)
 
 
 @pytest.mark.parametrize("H,B", [(64, 40), (512, 48), (512, 70)])
