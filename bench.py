@@ -503,6 +503,7 @@ def main():
             ctc_saturation(out, torch, A, T, U)
             del net, feats, dev_bufs
             torch.cuda.empty_cache()
+            small_configs(out, torch)
             cfg4_share(out, torch)
             cfg5_fp16(out, torch)
         if cpu_base is not None:
@@ -837,6 +838,46 @@ def cfg5_fp16(out, torch):
                                     "operand_dtype fp16 (float16 forward / bfloat16 backward operands, fp32 "
                                     "accumulate, float64 CTC lattices), HBM-resident features",
                         "dtype": "f16 operands / f32 accumulate", **res}
+
+
+def small_configs(out, torch):
+    """BASELINE configs[0] and [1] at their real sizes, minibatch 1 (the reference's own mode: one utterance per
+    costAndGrad call): T=200 A=28 2x512 (temporalLayer 1, inputDim 615) U=20 and the TIMIT shape T=300 A=62 3x1024
+    (temporalLayer 2, inputDim 943) U=30, fp32, HBM-resident features -- side fields, never `value`.  They are
+    launch- and latency-bound (a step is 0.5-1 ms of 40-odd launches and 2 x (T - 1) dependent recurrent steps)."""
+    from nnets import brnnet
+    import _sctc
+    L = _sctc.lib()
+    for name, (D, A, H, NL, TL, T, U) in (("cfg1_minibatch1", (615, 28, 512, 2, 1, 200, 20)),
+                                           ("cfg2_minibatch1", (943, 62, 1024, 3, 2, 300, 30))):
+        np.random.seed(0)
+        net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=1, gemm="f32")
+        net.initParams()
+        g = torch.Generator(device="cuda")
+        g.manual_seed(2)
+        feats = torch.randn(T, D, device="cuda", generator=g)
+        rs = np.random.RandomState(2)
+        labels = [rs.randint(1, A, size=U).astype(np.int32)]
+        for _ in range(3):
+            net.costAndGradBatch(None, labels, feats_dev=feats, T_b=[T])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 20
+        for _ in range(n):
+            net.costAndGradBatch(None, labels, feats_dev=feats, T_b=[T])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        L.sctc_brnn_set_profiling(net._h, 1)
+        net.costAndGradBatch(None, labels, feats_dev=feats, T_b=[T])
+        arr = (ctypes.c_float * len(PHASES))()
+        L.sctc_brnn_phase_ms(net._h, arr)
+        L.sctc_brnn_set_profiling(net._h, 0)
+        ph = dict(zip(PHASES, [float(v) for v in arr]))
+        out[name] = {"workload": "T=%d A=%d %dx%d BRNN (temporalLayer %d, inputDim %d) U=%d, minibatch 1, fp32" % (T, A, NL, H, TL, D, U),
+                     "value": T / dt, "unit": "frames/s", "ms_per_utterance": dt * 1e3, "phase_ms": ph,
+                     "us_per_recurrent_step": (ph["fwd_rec"] + ph["bwd_rec"]) * 1e3 / (2 * (T - 1))}
+        del net, feats
+    torch.cuda.empty_cache()
 
 
 def cfg4_share(out, torch):

@@ -2,9 +2,10 @@
 // the device counterpart of ctc_fast/ctc-loss/ctc_fast.pyx:13-152 for label rows of up to 512
 // lattice states (2U+1 <= 512: every shape of BASELINE configs[0..3]; 2, 4 or 8 states per lane).
 //
-// One workgroup = one utterance = two waves: wave 0 runs the scaled alpha recursion
-// (ctc_fast.pyx:42-76), wave 1 the beta recursion (:79-114) as an alpha pass on the reversed
-// problem (ctc_kernels.hip, header).  With Ta = T/2:
+// One workgroup = one utterance: wave 0 runs the scaled alpha recursion (ctc_fast.pyx:42-76), wave 1
+// the beta recursion (:79-114) as an alpha pass on the reversed problem (ctc_kernels.hip, header);
+// with helper waves (HELP, batches of up to 256 utterances) waves 2..5 form the gradient of phase 1
+// from the rows the two hand over through an LDS ring.  With Ta = T/2:
 //
 //   phase 0   alpha walks t = 0 .. Ta-1, beta walks t = T-1 .. Ta; each STORES its normalised rows
 //   barrier   (the workgroup's own stores, same CU / same L2)
@@ -13,7 +14,8 @@
 //             t = Ta-1 .. 0 against the stored alpha rows.  Each wave forms ab = alpha*beta
 //             (:117-119), the per-label sums (:120-131), absum (:133-136) and the frame's
 //             gradient row (:138-145) and writes it: every frame's gradient is produced exactly
-//             once, by the wave whose recursion reaches it second.
+//             once, from the recursion that reaches it second (by that wave itself, or by its two
+//             helper waves: see HELP below).
 //
 // Against ctc_lattice_kernel + ctc_grad_kernel (both lattices stored in float64 over a 64K-wide
 // row, both read back by a third kernel: 4 lattice passes over HBM) a lattice element is stored
@@ -38,13 +40,15 @@
 // Summation order.  absum[t] divides every state's product by ITS label's probability before it
 // sums (:125-131): that order is kept (the per-label form sum_k g_k / y_k is the same number until
 // the products are denormal -- then it is off by 1e-3, and the reference's value is what
-// counts).  The division is a multiplication with the correctly rounded reciprocal, computed once
-// per label state and block of frames, off the recursion's dependency chain.  The sums themselves
+// counts).  The division is a multiplication with the reciprocal (float32 probabilities: the
+// hardware estimate + two Newton steps, <= 1 ulp; float64 probabilities, which may be denormal: the
+// IEEE division), formed once per symbol and frame, off the recursion's dependency chain.  The sums themselves
 // are taken as fixed trees (bit-reproducible run to run; the reference adds in ascending state
 // order: differences are in the last bits, the float64 golden vectors hold at 1e-11 / 1e-9).
 #include <mutex>
 #include <type_traits>
 
+// frames per block of the two-wave form (4: 190 registers, two waves per SIMD; 8: 296, one)
 #ifndef SCTC_FUSED_PF2
 #define SCTC_FUSED_PF2 4
 #endif

@@ -15,6 +15,9 @@ if "hbm_resident" in d:
 rr = d.get("roofline_recurrent", {})
 if "by_minibatch" in rr:
     print("rec by minibatch", {k: (round(v["us_per_time_step"], 2), round(v["frac_of_f32_mfma_peak"], 3)) for k, v in rr["by_minibatch"].items()})
+for k in ("cfg1_minibatch1", "cfg2_minibatch1"):
+    if k in d:
+        print(k, round(d[k]["value"]), "frames/s", round(d[k]["ms_per_utterance"], 3), "ms", {a: round(b, 3) for a, b in d[k]["phase_ms"].items()})
 c4 = d.get("cfg4_share")
 if c4:
     print("cfg4 share", round(c4["value"]), round(c4["ms_per_step"], 2), {a: round(b, 2) for a, b in c4["phase_ms"].items()})
