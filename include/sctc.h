@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SCTC_ABI_VERSION 4
+#define SCTC_ABI_VERSION 5
 
 #define SCTC_OK 0
 #define SCTC_ERR_ARG (-1)       /* bad argument (the reference raises ValueError/AssertionError) */
@@ -227,6 +227,22 @@ int sctc_brnn_cost_and_grad_async(sctc_brnn_t h, const sctc_minibatch* mb, int32
  * its workgroups resident at once) is being placed. */
 void* sctc_brnn_grad_event(sctc_brnn_t h, int32_t index);
 int sctc_stream_wait_event(void* stream, void* event);
+/* SURVEY 8(e) (the reference has no multi-GPU path): the ONE exchange step of the data-parallel path as a C entry --
+ * the sum of the weight gradients over the ranks of an RCCL communicator, overlapped with the backward pass that
+ * sctc_brnn_cost_and_grad_async queued on `compute_stream`.  `side_stream` (a stream of its own) waits for the
+ * event of each layer's gradient in the order the backward pass finishes them (output layer first; the layers above
+ * the temporal layer and the recurrent pair after BPTT has retired) and starts ncclAllReduce(sum, float, in place)
+ * on that layer's slice of the flat gradient buffer; `side_dev` (nullable: double[side_count] on the device, e.g.
+ * [n_valid, cost_sum, regcost, has_regcost], produced on the compute stream) is reduced last; on return
+ * `compute_stream` has been made to wait for all of it (nothing is synchronised with the host).
+ *   rccl_comm        an ncclComm_t the caller created for this rank's device (ncclCommInitRank), one per rank
+ *   backward_queued  0: this rank queued no backward pass this step (empty shard, gradient buffer zeroed on the
+ *                    compute stream): the side stream is ordered behind the compute stream as a whole
+ * librccl.so is resolved with dlopen at first use (libsctc_hip.so does not link against it): SCTC_ERR_STATE if it is
+ * not there.  The Python host side (dist_sgd.allreduce_overlapped) issues the same sequence through
+ * torch.distributed; this entry is for hosts that own their communicator. */
+int sctc_brnn_allreduce_grads(sctc_brnn_t h, void* rccl_comm, void* compute_stream, void* side_stream,
+                              double* side_dev, int32_t side_count, int32_t backward_queued);
 /* synchronises `stream` and reports a failure of the asynchronous work queued on it:
  * SCTC_ERR_TIMEOUT when a persistent recurrent kernel gave up waiting for its peers (results of
  * that call are then meaningless), SCTC_OK otherwise */

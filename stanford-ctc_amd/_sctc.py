@@ -99,6 +99,7 @@ PROTOTYPES = {
     "sctc_nesterov_step": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_float,
                                           ctypes.c_float, ctypes.c_float, ctypes.c_float, vp,
                                           vp]),
+    "sctc_brnn_allreduce_grads": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32]),
     "sctc_sumsq_reg": (ctypes.c_int, [vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int64,
                                       c_i64p, ctypes.c_int32, vp, vp, ctypes.c_size_t, vp]),
     "sctc_nesterov_step_reg": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_float,
@@ -189,7 +190,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if L.sctc_abi_version() != 4:
+        if L.sctc_abi_version() != 5:
             raise ImportError("libsctc_hip.so ABI version mismatch")
         _lib = L
         # shared-device mode is not guessed here: the library finds out by itself how many processes use

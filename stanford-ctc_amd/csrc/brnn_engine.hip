@@ -14,6 +14,10 @@
 #include <vector>
 
 #include "common.h"
+#include <dlfcn.h>
+
+#include <mutex>
+
 #include "ctc_kernels.h"
 #include "elementwise.h"
 #include "gemm_f32.h"
@@ -1038,6 +1042,93 @@ int sctc_stream_wait_event(void* stream, void* event)
     SCTC_CHECK_ARG(event, "stream_wait_event: null event");
     SCTC_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
     return SCTC_OK;
+}
+
+// ---- the gradient exchange as a C entry (round 5; the Python host side does the same through
+// torch.distributed in dist_sgd.allreduce_overlapped).  RCCL is resolved with dlopen at first use: libsctc_hip.so
+// itself has no link dependency on it.
+namespace {
+struct Rccl {
+    typedef int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    typedef const char* (*ErrStr)(int);
+    void* lib = nullptr;
+    AllReduce all_reduce = nullptr;
+    ErrStr err_str = nullptr;
+    bool tried = false;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+}  // namespace
+
+int sctc_brnn_allreduce_grads(sctc_brnn_t h, void* rccl_comm, void* compute_stream, void* side_stream,
+                              double* side_dev, int32_t side_count, int32_t backward_queued)
+{
+    SCTC_CHECK_ARG(h && rccl_comm, "brnn_allreduce_grads: null handle / communicator");
+    SCTC_CHECK_ARG(h->grads, "brnn_allreduce_grads: the model has no gradient buffer (train = 0)");
+    SCTC_CHECK_ARG(side_stream && side_stream != compute_stream, "brnn_allreduce_grads: needs a side stream of its own");
+    SCTC_CHECK_ARG(side_count >= 0 && (side_count == 0 || side_dev), "brnn_allreduce_grads: bad side message");
+    {
+        std::lock_guard<std::mutex> lock(g_rccl_mu);
+        if (!g_rccl.tried) {
+            g_rccl.tried = true;
+            const char* names[3] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+            for (int k = 0; k < 3 && !g_rccl.lib; ++k) g_rccl.lib = dlopen(names[k], RTLD_NOW | RTLD_GLOBAL);
+            if (g_rccl.lib) {
+                g_rccl.all_reduce = (Rccl::AllReduce)dlsym(g_rccl.lib, "ncclAllReduce");
+                g_rccl.err_str = (Rccl::ErrStr)dlsym(g_rccl.lib, "ncclGetErrorString");
+            }
+        }
+    }
+    if (!g_rccl.all_reduce)
+        return set_error(SCTC_ERR_STATE, "brnn_allreduce_grads: librccl.so (ncclAllReduce) could not be loaded");
+    hipStream_t cs = (hipStream_t)compute_stream, ss = (hipStream_t)side_stream;
+    constexpr int NCCL_SUM = 0, NCCL_FLOAT = 7, NCCL_DOUBLE = 8;      // rccl.h: ncclSum, ncclFloat32, ncclFloat64
+    auto reduce = [&](void* p, size_t n, int dt) -> int {
+        const int rc = g_rccl.all_reduce(p, p, n, dt, NCCL_SUM, rccl_comm, ss);
+        if (rc != 0)
+            return set_error(SCTC_ERR_HIP, "ncclAllReduce failed: %s", g_rccl.err_str ? g_rccl.err_str(rc) : "?");
+        return SCTC_OK;
+    };
+    // an event of our own orders "everything queued on the compute stream so far" in front of the side stream
+    hipEvent_t ev = nullptr;
+    SCTC_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    int rc = SCTC_OK;
+    auto after_compute = [&]() -> int {
+        SCTC_HIP_TRY(hipEventRecord(ev, cs));
+        SCTC_HIP_TRY(hipStreamWaitEvent(ss, ev, 0));
+        return SCTC_OK;
+    };
+    if (!backward_queued) rc = after_compute();   // no backward pass this step: the buffer was zeroed on the compute stream
+    // buckets in the order the backward pass finishes them: output layer first, the recurrent pair right behind
+    // the temporal layer's BPTT (nnets/brnnet.py gradBuckets)
+    const int n = (int)h->tinfo.size();
+    auto slice_end = [&](int i) -> int64_t { return i + 1 < n ? h->tinfo[i + 1].offset : h->param_elems; };
+    for (int i = h->NL; i >= 0 && rc == SCTC_OK; --i) {
+        const int w = weight_index(h, i);
+        if (backward_queued) {
+            const hipError_t e = hipStreamWaitEvent(ss, h->grad_ev[w], 0);
+            if (e != hipSuccess) { rc = set_error(SCTC_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(e)); break; }
+        }
+        rc = reduce(h->grads + h->tinfo[w].offset, (size_t)(slice_end(w + 1) - h->tinfo[w].offset), NCCL_FLOAT);   // W and b
+        if (rc == SCTC_OK && i == h->TL) {
+            for (int k : {wf_index(h), wb_index(h)}) {
+                if (backward_queued) (void)hipStreamWaitEvent(ss, h->grad_ev[k], 0);
+                rc = reduce(h->grads + h->tinfo[k].offset, (size_t)(slice_end(k) - h->tinfo[k].offset), NCCL_FLOAT);
+                if (rc != SCTC_OK) break;
+            }
+        }
+    }
+    if (rc == SCTC_OK && side_count > 0) {
+        rc = after_compute();                      // the side message is produced on the compute stream
+        if (rc == SCTC_OK) rc = reduce(side_dev, (size_t)side_count, NCCL_DOUBLE);
+    }
+    if (rc == SCTC_OK) {                           // the compute stream continues behind the collectives
+        hipError_t e = hipEventRecord(ev, ss);
+        if (e == hipSuccess) e = hipStreamWaitEvent(cs, ev, 0);
+        if (e != hipSuccess) rc = set_error(SCTC_ERR_HIP, "brnn_allreduce_grads: %s", hipGetErrorString(e));
+    }
+    (void)hipEventDestroy(ev);                     // (released by the runtime once the recorded work has run)
+    return rc;
 }
 
 int sctc_brnn_check(sctc_brnn_t h, void* stream)

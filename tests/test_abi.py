@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(sctc):
     for n in names:
         assert hasattr(L, n), "libsctc_hip.so does not export %s" % n
     assert sorted(sctc.PROTOTYPES) == names, "ctypes prototypes out of sync with include/sctc.h"
-    assert L.sctc_abi_version() == 4        # v4: sctc_device_pci_bus_id (v3: shared-device mode, recurrent_path)
+    assert L.sctc_abi_version() == 5        # v5: sctc_brnn_allreduce_grads (v4: sctc_device_pci_bus_id; v3: shared-device mode, recurrent_path)
 
 
 def test_struct_mirrors_match_the_header(sctc, tmp_path):
@@ -75,6 +75,8 @@ def test_argument_errors_need_no_gpu(sctc):
     bad = sctc.BrnnConfig(20, 1, 30, 3, 2, 10, 1, 20.0, 0.0, 1)
     assert L.sctc_brnn_query(ctypes.byref(bad), ctypes.byref(sizes)) == -1
     assert b"dimensions" in L.sctc_last_error()
+    # the C-level collective entry rejects a missing handle / communicator before anything is touched
+    assert L.sctc_brnn_allreduce_grads(None, None, None, None, None, 0, 1) == -1
     with pytest.raises(ValueError):
         sctc.check(-1, "x")
     T = np.array([5], dtype=np.int32)

@@ -311,3 +311,62 @@ def test_bench_single_rank_rccl():
     # bookkeeping only (a one-rank all-reduce moves no data): measured +1 %; the bound is loose because
     # three timed steps on a box shared with the harness are noisy
     assert d["ms_per_step"] < 1.15 * s["ms_per_step"] + 1.0, (d["ms_per_step"], s["ms_per_step"])
+
+
+def test_c_level_allreduce_entry_one_rank_rccl():
+    """sctc_brnn_allreduce_grads (round 5, SURVEY 8(b)'s sketched entry): the per-layer RCCL all-reduces queued behind
+    the engine's gradient events by the LIBRARY, on a communicator the host created itself (ctypes on librccl.so,
+    one rank: the sum over one rank must leave gradients and the side message bit for bit what the synchronous step
+    gives), on a side stream while the backward pass is still queued; argument errors; a second step reuses it."""
+    import ctypes
+    import torch
+    import _sctc
+    from nnets import brnnet
+    from oracle import brnn as obrnn
+    rccl = ctypes.CDLL("librccl.so.1")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    L = _sctc.lib()
+    rs = np.random.RandomState(12)
+    D, A, H, NL, TL, B = 24, 20, 64, 3, 2, 7
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    Ts = [int(t) for t in rs.randint(3, 25, size=B)]
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 6)).astype(np.int32) for T in Ts]
+    from tests.test_gpu_brnn import host_stack
+    net = brnnet.NNet(D, A, H, NL, max(Ts), temporalLayer=TL, maxUtts=B)
+    net.setParams(host_stack(params))
+    costs, _, skips = net.costAndGradBatch(datas, labs)
+    want = net.grad.flat.clone()
+    side = torch.tensor([3.0, 1.5, 0.25, 1.0], dtype=torch.float64, device="cuda")
+    side_stream = torch.cuda.Stream()
+    for step in range(2):
+        net.grad.flat.zero_()
+        cost_dev, skip_dev = net.costAndGradBatchAsync(datas, labs)
+        rc = L.sctc_brnn_allreduce_grads(net._h, comm, _sctc.current_stream_ptr(), ctypes.c_void_p(side_stream.cuda_stream),
+                                         ctypes.c_void_p(side.data_ptr()), 4, 1)
+        _sctc.check(rc, "allreduce_grads")
+        net.checkAsync()
+        torch.cuda.synchronize()
+        assert torch.equal(net.grad.flat, want)
+        np.testing.assert_array_equal(cost_dev.cpu().numpy(), costs)
+        np.testing.assert_array_equal(side.cpu().numpy(), [3.0, 1.5, 0.25, 1.0])
+    # no backward pass queued (an empty shard): the zeroed buffer is reduced behind the compute stream as a whole
+    net.grad.flat.zero_()
+    _sctc.check(L.sctc_brnn_allreduce_grads(net._h, comm, _sctc.current_stream_ptr(), ctypes.c_void_p(side_stream.cuda_stream),
+                                            None, 0, 0), "allreduce_grads")
+    torch.cuda.synchronize()
+    assert not net.grad.flat.any()
+    with pytest.raises(ValueError):      # the compute stream is not a side stream
+        _sctc.check(L.sctc_brnn_allreduce_grads(net._h, comm, _sctc.current_stream_ptr(), _sctc.current_stream_ptr(), None, 0, 1), "x")
+    with pytest.raises(ValueError):
+        _sctc.check(L.sctc_brnn_allreduce_grads(net._h, None, None, ctypes.c_void_p(side_stream.cuda_stream), None, 0, 1), "x")
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    rccl.ncclCommDestroy(comm)
