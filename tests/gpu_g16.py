@@ -36,7 +36,11 @@ def check():
     g.manual_seed(1)
     worst = 0.0
     cases = [(256, 256, 64), (256, 256, 128), (512, 256, 192), (300, 260, 72), (1000, 520, 200), (264, 1824, 1824),
-             (2048, 2048, 4096), (1824, 1824, 8000), (40, 24, 8), (8, 8, 640), (256, 64, 2048), (777 * 8, 33 * 8, 1824)]
+             (2048, 2048, 4096), (1824, 1824, 8000), (40, 24, 8), (8, 8, 640), (256, 64, 2048), (777 * 8, 33 * 8, 1824),
+             # the input-layer weight gradient of cfg-5 at its real shape (dW1 = delta_1^T X: 2048 x 640 -- inputDim 615 padded like the engine pads it -- over 8000 /
+             # 64000 frames; VERDICT r04 weak #3: the network-level bound on dW1 is wide by nature, the contraction
+             # itself is pinned here) and the output layer's (33 symbols padded to 64)
+             (2048, 640, 8000), (2048, 640, 64000), (64, 2048, 64000)]
     for (M, N, K) in cases:
         for kc in (1, 0):
             for dt, tt in ((_sctc.F16, torch.float16), (_sctc.BF16, torch.bfloat16)):

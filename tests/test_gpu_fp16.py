@@ -115,6 +115,16 @@ def test_gemm_h16_all_layouts(mods):
                                     4, 4, 4, 4, None, 0, _sctc.F32, None, 0, None), "gemm_h16")
 
 
+def test_gemm_g16_public_entry_all_shapes(mods, monkeypatch):
+    """the LDS-DMA 16-bit GEMM (csrc/gemm_g16.hip) through sctc_gemm_h16 with SCTC_OPERANDS_16BIT: tests/gpu_g16.py's
+    check -- ragged shapes with row / column / k tails, both layouts, both types, NaN-poisoned padding, and the cfg-5
+    weight-gradient shapes at their real sizes (dW1: 2048 x 615 over 64000 frames) -- against the float64 product of
+    the 16-bit operands, 2e-6 of sum |a||b|"""
+    from tests import gpu_g16
+    monkeypatch.setenv("SCTC_H16_TILE", "1")
+    assert gpu_g16.check()
+
+
 @pytest.mark.parametrize("name", ["cfg5", "cfg3"])
 def test_fp16_scaled_fixture(mods, golden, name):
     """the scaled cfg-5 / cfg-3 twins (weights, data, labels of the rnnetcpu golden fixture):
