@@ -1618,6 +1618,7 @@ void recurrent_set_shared_device_mode(int on) { g_shared_mode.store(on ? 1 : 0, 
 namespace {
 
 static constexpr double LEASE_WAIT_S = 30.0;
+static constexpr int Q1_MIN_B = 4;     // fewest utterances the single-chain flag kernel takes by default (below: the sentinel / VALU kernel; measured round 5, tools/rec_small_bench.py: 3 utterances 3.9 vs 4.6 us per step, 4: 4.9 vs 4.6, 5: 7.0 vs 4.5 at H = 1824)
 static double now_s()
 {
     struct timespec ts;
@@ -1956,7 +1957,33 @@ static int launch_recurrent_one(const RecArgs& a, const LaunchCtx& cx)
     }
     // measured at H=1824: 2.5 us per step for one utterance + ~1.2 us per further one (VALU FMAs),
     // against 7.4 us for the flag/MFMA kernel: worth it up to 5 utterances
-    if (a.B <= 5 && a.variant != 1) {
+    // 4..16 utterances are ONE 16-utterance chain: the flag kernel of the 17..32 case with a single chain per direction
+    // (one workgroup per CU instead of two).  Round 5 (VERDICT r04: "7.16 us at B = 16 is suspicious" -- it was): at
+    // H = 1824 it needs 4.66 / 4.57 / 4.80 / 4.97 us per step at 6 / 8 / 12 / 16 utterances where the sentinel / MFMA
+    // kernel below needs 4.92 / 5.00 / 6.09 / 7.16 (H = 2048: 5.45 against 7.31 at 16), with bit-identical costs and
+    // gradients (tools/rec_mid_bench.py): it is the default for fp32 operands; variant 42 keeps the sentinel kernel.
+    // At 4 and 5 utterances it also beats the sentinel / VALU kernel (whose step grows by 1 us per utterance and jumps at
+    // the fifth: 2.2 / 3.0 / 3.9 / 4.9 / 7.0 us for 1..5): variant 43 keeps that one up to 8, 44 forces this one from 1.
+    if ((!a.prec16 || a.B <= 5) && (a.B > Q1_MIN_B - 1 || a.variant == 44) && a.B <= 16 && a.variant != 1 && a.variant != 42 && a.variant != 43 &&
+        2 * nwg <= cx.cus) {
+        RecKernel qk = nullptr;
+        int ncq = 0, nreg = 0;
+        switch (nwg) {
+            case 32:  qk = brnn_recurrent_q_kernel<8, 0>;   ncq = 8;  nreg = 0;  break;  // H = 512
+            case 64:  qk = brnn_recurrent_q_kernel<16, 0>;  ncq = 16; nreg = 0;  break;  // H = 1024
+            case 114: qk = brnn_recurrent_q_kernel<29, 10>; ncq = 29; nreg = 10; break;  // H = 1824
+            case 128: qk = brnn_recurrent_q_kernel<32, 13>; ncq = 32; nreg = 13; break;  // H = 2048
+            default: break;
+        }
+        if (qk) {
+            RecArgs b = a;
+            b.variant = 2;      // linear block -> (chain, producer) map: chain = direction, tile 0 only
+            const size_t smem = sizeof(float4) * ((size_t)4 * (ncq - nreg) * 64 + 3 * 64);
+            SCTC_TRY(launch_persistent(qk, 2 * nwg, smem, 2, 0, b, cx, &done));
+            if (done) return SCTC_OK;
+        }
+    }
+    if ((a.B <= 5 || (a.B <= 8 && a.variant == 43)) && a.variant != 1) {     // 43: the 8-utterance instantiation up to 8 (experiment)
         RecKernel sk = nullptr;
         const bool s4 = a.B <= 4;
         switch (a.Hp / 32) {
@@ -1990,29 +2017,6 @@ static int launch_recurrent_one(const RecArgs& a, const LaunchCtx& cx)
         const size_t smem = (((size_t)16 * (a.Hp + 8) * 2 + 15) / 16) * 16 + 3 * 64 * sizeof(float4);
         if (hk && smem <= 160 * 1024) {
             SCTC_TRY(launch_persistent(hk, 2 * nwg, smem, 1, (size_t)2 * a.n_xrows * a.Hp * 2, a, cx, &done));
-            if (done) return SCTC_OK;
-        }
-    }
-    // 6..16 utterances are ONE 16-utterance chain: the flag kernel of the 17..32 case with a single chain per direction
-    // (one workgroup per CU instead of two).  Round 5 (VERDICT r04: "7.16 us at B = 16 is suspicious" -- it was): at
-    // H = 1824 it needs 4.66 / 4.57 / 4.80 / 4.97 us per step at 6 / 8 / 12 / 16 utterances where the sentinel / MFMA
-    // kernel below needs 4.92 / 5.00 / 6.09 / 7.16 (H = 2048: 5.45 against 7.31 at 16), with bit-identical costs and
-    // gradients (tools/rec_mid_bench.py): it is the default for fp32 operands; variant 42 keeps the sentinel kernel.
-    if (!a.prec16 && a.B > 5 && a.B <= 16 && a.variant != 1 && a.variant != 42 && 2 * nwg <= cx.cus) {
-        RecKernel qk = nullptr;
-        int ncq = 0, nreg = 0;
-        switch (nwg) {
-            case 32:  qk = brnn_recurrent_q_kernel<8, 0>;   ncq = 8;  nreg = 0;  break;  // H = 512
-            case 64:  qk = brnn_recurrent_q_kernel<16, 0>;  ncq = 16; nreg = 0;  break;  // H = 1024
-            case 114: qk = brnn_recurrent_q_kernel<29, 10>; ncq = 29; nreg = 10; break;  // H = 1824
-            case 128: qk = brnn_recurrent_q_kernel<32, 13>; ncq = 32; nreg = 13; break;  // H = 2048
-            default: break;
-        }
-        if (qk) {
-            RecArgs b = a;
-            b.variant = 2;      // linear block -> (chain, producer) map: chain = direction, tile 0 only
-            const size_t smem = sizeof(float4) * ((size_t)4 * (ncq - nreg) * 64 + 3 * 64);
-            SCTC_TRY(launch_persistent(qk, 2 * nwg, smem, 2, 0, b, cx, &done));
             if (done) return SCTC_OK;
         }
     }

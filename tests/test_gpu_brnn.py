@@ -473,10 +473,10 @@ def test_recurrent_small_batch_kernel_layer_sizes(mods, monkeypatch, H):
 @pytest.mark.parametrize("variant", ["0", "42"])
 @pytest.mark.parametrize("H,B", [(512, 6), (512, 16), (1824, 9), (2048, 12), (1024, 7), (1824, 16)])
 def test_recurrent_mid_batch_kernel(mods, monkeypatch, H, B, variant):
-    """6..16 utterances: since round 5 the flag kernel with ONE chain per direction (brnn_recurrent_q_kernel on half
-    its grid; variant 0), before that the sentinel-exchange MFMA kernel (brnn_recurrent_m_kernel; variant 42): ragged
-    minibatch against the one-workgroup-per-CU flag kernel (SCTC_REC_VARIANT=1) and, at H=512, the oracle; the two
-    agree bit for bit"""
+    """6..16 utterances (4..16 since the crossover measurement): since round 5 the flag kernel with ONE chain per
+    direction (brnn_recurrent_q_kernel on half its grid; variant 0), before that the sentinel-exchange MFMA kernel
+    (brnn_recurrent_m_kernel; variant 42): ragged minibatch against the one-workgroup-per-CU flag kernel
+    (SCTC_REC_VARIANT=1) and, at H=512, the oracle; the two agree bit for bit"""
     _, brnnet, obrnn, _ = mods
     rs = np.random.RandomState(31 * H + B)
     D, A, NL, TL = 32, 33, 2, 1
@@ -626,3 +626,42 @@ def test_large_minibatch_recurrence_pipelined_is_bit_identical(mods, monkeypatch
         ok = ~sr
         np.testing.assert_allclose(res[0][0][ok], cr[ok], rtol=1e-4)
         assert rel(res[0][2][NL + 1], gr["Wf"]) < 2e-3
+
+
+@pytest.mark.parametrize("H,B", [(512, 4), (512, 5), (1824, 4), (2048, 5), (1024, 3)])
+def test_recurrent_small_batch_crossover(mods, monkeypatch, H, B):
+    """1..3 utterances run the sentinel / VALU kernel, 4 and 5 the single-chain flag kernel since round 5 (a step of the
+    VALU kernel grows by 1 us per utterance: 4.9 / 7.0 us at 4 / 5 against 4.6 / 4.5): the default against the VALU
+    kernel forced up to 8 utterances (SCTC_REC_VARIANT=43), the flag kernel forced from 1 (44) and, at H=512, the
+    oracle; ragged lengths"""
+    _, brnnet, obrnn, _ = mods
+    rs = np.random.RandomState(7 * H + B)
+    D, A, NL, TL = 32, 33, 2, 1
+    Ts = [int(t) for t in rs.randint(2, 26, size=B)]
+    Ts[0] = 26
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 8)).astype(np.int32) for T in Ts]
+    res = {}
+    for variant in ("0", "43", "44"):
+        monkeypatch.setenv("SCTC_REC_VARIANT", variant)
+        net = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
+        costs, _, skips = net.costAndGradBatch(datas, labs)
+        assert net.recurrentPath()[:2] == (1, 1)
+        res[variant] = (costs.copy(), skips.copy(), _all_grads(net, NL))
+        if variant == "0" and H == 512:
+            with np.errstate(all="ignore"):
+                costs_ref, g_ref, skips_ref, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+            np.testing.assert_array_equal(skips, skips_ref)
+            np.testing.assert_allclose(costs[~skips_ref], costs_ref[~skips_ref], rtol=1e-4)
+            check_grads(net, g_ref, NL)
+        del net
+    ok = ~res["0"][1]
+    for other in ("43", "44"):
+        np.testing.assert_array_equal(res["0"][1], res[other][1])
+        np.testing.assert_allclose(res["0"][0][ok], res[other][0][ok], rtol=1e-5)
+        for a, b in zip(res["0"][2], res[other][2]):
+            assert rel(a, b) < 2e-4
+    same_as = "44" if B >= 4 else "43"           # which forced kernel IS the default at this size
+    for a, b in zip(res["0"][2], res[same_as][2]):
+        np.testing.assert_array_equal(a, b)
