@@ -524,6 +524,8 @@ def sec_recdbg(sync=0, B=32):
         a = both[ps, 256:].reshape(512, 8)
         ids = np.nonzero(a[:, 7] != 0)[0]
         w = a[ids]
+        if len(w) == 0:          # a kernel without the all-workgroup stamps (the sentinel kernels)
+            continue
         t0 = w[:, 0].min()
         pub = (w[:, 5] - t0) * 0.01
         seen = (w[:, 1] - t0) * 0.01
@@ -577,6 +579,8 @@ def sec_recdbg(sync=0, B=32):
         blocks_alone = sorted(int(ids[n]) for n in alone)
         print("   blocks alone:", blocks_alone[:64])
     names = ["wait", "load+mfma", "lds-reduce", "epilogue", "publish"]
+    if B <= 3:                   # brnn_recurrent_s_kernel stamps: start, rows staged (poll + LDS + barrier), FMAs + DPP, stored
+        names = ["poll+stage", "fma+dpp", "store", "-", "-"]
     for ps, pname in enumerate(("forward", "bptt")):
         for w in range(2):
             d = np.diff(st[ps, w, :, :6], axis=1) & 0xffffffff
