@@ -44,6 +44,7 @@ struct RecArgs {
                             // 8..23: both chains in one 8-wave workgroup, mode = variant - 8;
                             // 40: more than 32 utterances without the load / MFMA pipelining of round 5;
                             // 42: 6..16 utterances (fp32) on the sentinel / MFMA kernel instead of the single-chain flag kernel;
+                            // 45: 33..48 utterances as ONE launch of the one-workgroup-per-CU kernel (default: 32 + rest);
                             // 43: the sentinel / VALU kernel for up to 8 utterances (default: up to 3); 44: the single-chain
                             //     flag kernel from 1 utterance (default: from 4)
     unsigned* debug;        // nullable: s_memtime stamps [2 wgs][16 steps][8] for steps 64..79

@@ -2113,13 +2113,20 @@ int launch_recurrent(const RecArgs& a_in, hipStream_t stream, int* path)
     // utterances are independent: more than 128 run as consecutive launches of <= 128 (sorted by
     // length, so a later launch covers no more steps than its first utterance has frames)
     constexpr int MAXB = 128;
-    for (int b0 = 0; b0 < a_in.B; b0 += MAXB) {
+    for (int b0 = 0; b0 < a_in.B;) {
+        int nb = std::min(MAXB, a_in.B - b0);
+        // 33..48 utterances: the two-chain kernel on the first 32 (6.8 us per step) and the single-chain kernel on the
+        // rest (4.6-5.0, and only as many steps as ITS longest utterance has) beat the one-workgroup-per-CU kernel on all
+        // of them (12.2 / 13.0 us per step at 40 / 48; round 5, tools/rec_large_bench.py); variant 45 keeps one launch
+        if (nb > 32 && nb <= 48 && a.variant == 0 && !a.prec16) nb = 32;
         RecArgs c = a;
         c.b_off = a_in.b_off + b0;
         c.T_b = a_in.T_b + b0;
-        c.B = std::min(MAXB, a_in.B - b0);
+        c.B = nb;
         if (a_in.T_host) c.Tmax = std::min(a_in.Tmax, (int)a_in.T_host[b0]);
+        if (c.variant == 45) c.variant = 0;
         SCTC_TRY(launch_recurrent_one(c, cx));
+        b0 += nb;
     }
     return SCTC_OK;
 }

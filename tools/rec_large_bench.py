@@ -28,7 +28,7 @@ for B in [int(v) for v in sys.argv[1:]] or [48, 64, 96, 128]:
     labels = [rs.randint(1, A, size=T // 10).astype(np.int32) for _ in range(B)]
     Ts = [T] * B
     res, grads = {}, {}
-    for variant in ("0", "40"):
+    for variant in ("0", os.environ.get("REC_BASE_VARIANT", "40")):
         os.environ["SCTC_REC_VARIANT"] = variant
         np.random.seed(0)
         net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B)
@@ -49,7 +49,10 @@ for B in [int(v) for v in sys.argv[1:]] or [48, 64, 96, 128]:
                         "path": list(net.recurrentPath())}
         del net
         torch.cuda.empty_cache()
-    same = bool((grads["0"][0] == grads["40"][0]).all() and torch.equal(grads["0"][1], grads["40"][1]))
-    print(json.dumps({"H": H, "B": B, "pipelined": res["0"], "rounds_1_4": res["40"], "bit_identical": same}), flush=True)
-    assert same
+    same = bool((grads["0"][0] == grads[os.environ.get("REC_BASE_VARIANT", "40")][0]).all() and torch.equal(grads["0"][1], grads[os.environ.get("REC_BASE_VARIANT", "40")][1]))
+    print(json.dumps({"H": H, "B": B, "pipelined": res["0"], "rounds_1_4": res[os.environ.get("REC_BASE_VARIANT", "40")], "bit_identical": same}), flush=True)
+    base = os.environ.get("REC_BASE_VARIANT", "40")
+    gd = float((grads["0"][1] - grads[base][1]).double().norm() / grads[base][1].double().norm())
+    print("   gradient relative distance %.1e" % gd, flush=True)
+    assert same or (base != "40" and gd < 1e-4)       # other kernels: other summation order
     del feats
