@@ -2119,6 +2119,9 @@ int launch_recurrent(const RecArgs& a_in, hipStream_t stream, int* path)
         // rest (4.6-5.0, and only as many steps as ITS longest utterance has) beat the one-workgroup-per-CU kernel on all
         // of them (12.2 / 13.0 us per step at 40 / 48; round 5, tools/rec_large_bench.py); variant 45 keeps one launch
         if (nb > 32 && nb <= 48 && a.variant == 0 && !a.prec16) nb = 32;
+        // likewise 65..80: the four-tiles-per-wave kernel costs the same 21 us per step for 65 utterances as for 128
+        // (its tiles are all multiplied), 64 on the two-tile kernel (12.8) + up to 16 on the single-chain kernel (<= 5.0) less
+        else if (nb > 64 && nb <= 80 && a.variant == 0 && !a.prec16) nb = 64;
         RecArgs c = a;
         c.b_off = a_in.b_off + b0;
         c.T_b = a_in.T_b + b0;

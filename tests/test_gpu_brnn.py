@@ -607,7 +607,7 @@ def test_async_entry_matches_sync(mods):
     assert net.regCostDev().item() == pytest.approx(net.regcost, rel=1e-6)   # engine: fp32 partial sums
 
 
-@pytest.mark.parametrize("H,B", [(512, 52), (1824, 64), (2048, 100), (96, 70)])
+@pytest.mark.parametrize("H,B", [(512, 52), (1824, 64), (2048, 100), (96, 90)])
 def test_large_minibatch_recurrence_pipelined_is_bit_identical(mods, monkeypatch, H, B):
     """more than 32 utterances (brnn_recurrent_kernel<NTW>): round 5 issues the exchange loads of batch k+1 under the
     MFMAs of batch k; the same MFMAs on the same accumulators in the same order, so costs and every gradient are
@@ -679,12 +679,12 @@ def test_recurrent_small_batch_crossover(mods, monkeypatch, H, B):
         np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("H,B", [(512, 33), (512, 40), (1824, 48)])
+@pytest.mark.parametrize("H,B", [(512, 33), (512, 40), (1824, 48), (512, 66), (1824, 80)])
 def test_recurrence_33_to_48_utterances_as_two_launches(mods, monkeypatch, H, B):
     """33..48 utterances run as the two-chain kernel on the first 32 plus the single-chain (or, for 1..3 left over, the
     VALU) kernel on the rest since round 5 (8.97 / 11.4 / 12.2 us per step at 33 / 40 / 48 against 12.3 / 12.2 / 12.6 for
-    one launch of the one-workgroup-per-CU kernel, SCTC_REC_VARIANT=45): ragged lengths against that single launch
-    and, at H=512, the oracle"""
+    one launch of the one-workgroup-per-CU kernel, SCTC_REC_VARIANT=45), 65..80 as 64 + the rest (15.2 / 17.7 us at
+    65 / 80 against 20.0 / 20.3): ragged lengths against that single launch and, at H=512, the oracle"""
     _, brnnet, obrnn, _ = mods
     rs = np.random.RandomState(3 * H + B)
     D, A, NL, TL, Tmax = 24, 33, 3, 2, 18
@@ -705,10 +705,10 @@ def test_recurrence_33_to_48_utterances_as_two_launches(mods, monkeypatch, H, B)
                 cr, gr, sr, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
             np.testing.assert_array_equal(skips, sr)
             np.testing.assert_allclose(costs[~sr], cr[~sr], rtol=1e-4)
-            check_grads(net, gr, NL)
+            check_grads(net, gr, NL, tol=1e-3)      # (a boundary flip of one unit is within this: see test_recurrent_large_minibatch)
         del net
     ok = ~res[0][1]
     np.testing.assert_array_equal(res[0][1], res[1][1])
     np.testing.assert_allclose(res[0][0][ok], res[1][0][ok], rtol=1e-5)
     for a, b in zip(res[0][2], res[1][2]):
-        assert rel(a, b) < 2e-4
+        assert rel(a, b) < 1e-3
