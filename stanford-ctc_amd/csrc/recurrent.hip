@@ -237,6 +237,17 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
         ub[i] = (ng + 2 * i) * 16 + uj;
         uT[i] = ub[i] < p.B ? p.T_b[ub[i]] : 0;
     }
+    // Steps at which all 16 utterances of a tile are alive (j < the tile's shortest length) keep the tile's 1 KB of a chunk
+    // as [k quarter][utterance][4 units]: lane l = uj + 16 kq then reads / writes byte 16 l, a wave one contiguous KB.  The
+    // row-major form ([utterance][16 units]: consecutive lanes 64 bytes apart, every 16-lane group of a load touching all
+    // eight lines) stays for a tile's last steps, whose missing rows belong to the next step's block.
+    int tile_T[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        int m = 0x7fffffff;
+        for (int l = 0; l < 16; ++l) m = min(m, __builtin_amdgcn_readlane(uT[i], l));
+        tile_T[i] = p.variant == 46 ? 0 : m;       // 46: row-major throughout (rounds 1-5a; A/B)
+    }
     const int c_beg = kh * nch_half, c_end = c_beg + nch_half;
     // Which K half adds the other's partial sums to its own and stores the step's result of tile i.  Rounds 1-4: the
     // lower half, every tile (the upper half's waves sat out the epilogue: 1.8 us of a 128-utterance step).  Round 5:
@@ -266,6 +277,8 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
         bool active[NTW];
         int64_t orow[NTW];
         unsigned xin[NTW], xout[NTW];  // byte offsets (within a chunk) of the previous / this row
+        const unsigned xb_cur = (unsigned)__builtin_amdgcn_readfirstlane(p.xbase[j]);
+        const unsigned xb_prev = (unsigned)__builtin_amdgcn_readfirstlane(p.xbase[j > 0 ? j - 1 : 0]);
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             active[i] = j < uT[i];
@@ -274,10 +287,15 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
             // exchange rows are indexed by STEP (not by frame): all rows of one 256-byte-aligned
             // block are written in the same step in both time orders.  Finished / empty slots
             // read exchange row 0 (valid memory, result discarded).
-            const unsigned xrow = active[i] ? (unsigned)p.xbase[j] + (unsigned)ub[i] : 0u;
-            const unsigned prow = (active[i] && j > 0) ? (unsigned)p.xbase[j - 1] + (unsigned)ub[i] : 0u;
+            const unsigned xrow = active[i] ? xb_cur + (unsigned)ub[i] : 0u;
+            const unsigned prow = (active[i] && j > 0) ? xb_prev + (unsigned)ub[i] : 0u;
             xin[i] = prow * 64u + (unsigned)kq * 16u;
             xout[i] = xrow * 64u + (unsigned)kq * 16u;
+            const unsigned tile_row = (unsigned)(ng + 2 * i) * 16u;
+            if (j > 0 && j <= tile_T[i] && active[i])       // the tile was complete at step j - 1
+                xin[i] = (xb_prev + tile_row) * 64u + (unsigned)lane * 16u;
+            if (j < tile_T[i])
+                xout[i] = (xb_cur + tile_row) * 64u + (unsigned)lane * 16u;
         }
         // prefetch the per-frame additive term (independent of the recurrence)
         float4 pre4[NTW], act4[NTW];

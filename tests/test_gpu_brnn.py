@@ -607,11 +607,14 @@ def test_async_entry_matches_sync(mods):
     assert net.regCostDev().item() == pytest.approx(net.regcost, rel=1e-6)   # engine: fp32 partial sums
 
 
-@pytest.mark.parametrize("H,B", [(512, 52), (1824, 64), (2048, 100), (96, 90)])
+@pytest.mark.parametrize("H,B", [(512, 52), (1824, 64), (2048, 100), (96, 90), (512, 128)])
 def test_large_minibatch_recurrence_pipelined_is_bit_identical(mods, monkeypatch, H, B):
     """more than 32 utterances (brnn_recurrent_kernel<NTW>): round 5 issues the exchange loads of batch k+1 under the
     MFMAs of batch k; the same MFMAs on the same accumulators in the same order, so costs and every gradient are
-    bit for bit what SCTC_REC_VARIANT=40 (loads, fence, MFMAs: rounds 1-4) gives; ragged lengths, both passes"""
+    bit for bit what SCTC_REC_VARIANT=40 (loads, fence, MFMAs: rounds 1-4) gives; ragged lengths, both passes.
+    Likewise the exchange layout: a tile of 16 utterances is kept [k quarter][utterance][4 units] (a wave reads one
+    contiguous KB) while all 16 are alive and row-major for its last steps -- the ragged lengths here switch every
+    tile from one to the other; SCTC_REC_VARIANT=46 keeps row-major throughout: same numbers"""
     _, brnnet, obrnn, torch = mods
     rs = np.random.RandomState(H + B)
     D, A, NL, TL, Tmax = 24, 33, 3, 2, 14
@@ -621,17 +624,18 @@ def test_large_minibatch_recurrence_pipelined_is_bit_identical(mods, monkeypatch
     datas = [rs.randn(D, T) for T in Ts]
     labs = [rs.randint(1, A, size=max(1, T // 5)).astype(np.int32) for T in Ts]
     res = []
-    for variant in ("0", "40"):
+    for variant in ("0", "40", "46"):
         monkeypatch.setenv("SCTC_REC_VARIANT", variant)
         net = make_net(brnnet, (D, A, H, NL, TL, Tmax), params, maxUtts=B)
         costs, _, skips = net.costAndGradBatch(datas, labs)
         assert net.recurrentPath()[0] == 1
         res.append((costs.copy(), skips.copy(), [net.grad[i][0].copy_to_host().copy() for i in range(NL + 3)]))
         del net
-    np.testing.assert_array_equal(res[0][0], res[1][0])
-    np.testing.assert_array_equal(res[0][1], res[1][1])
-    for a, b in zip(res[0][2], res[1][2]):
-        np.testing.assert_array_equal(a, b)
+    for other in res[1:]:
+        np.testing.assert_array_equal(res[0][0], other[0])
+        np.testing.assert_array_equal(res[0][1], other[1])
+        for a, b in zip(res[0][2], other[2]):
+            np.testing.assert_array_equal(a, b)
     if H <= 512:
         with np.errstate(all="ignore"):
             cr, gr, sr, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
