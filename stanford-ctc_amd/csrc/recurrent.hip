@@ -528,6 +528,11 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
     const int uT = ub < p.B ? p.T_b[ub] : 0;
     // this chain is finished once its longest utterance (the tile's first) is
     const int Tchain = tile * 16 < p.B ? p.T_b[tile * 16] : 0;
+    // exchange layout of the tile's KB per chunk: in lane order while all 16 utterances are alive (j < tile_T), row-major
+    // for the tile's last steps -- see brnn_recurrent_kernel above (round 5; SCTC_REC_VARIANT=46: row-major throughout)
+    int tile_T = 0x7fffffff;
+    for (int l = 0; l < 16; ++l) tile_T = min(tile_T, __builtin_amdgcn_readlane(uT, l));
+    if (p.variant == 46) tile_T = 0;
 
     const int dbg_sel = (p.debug && chain == 0 && tid == 0) ? (wg == 0 ? 0 : (wg == nwg - 1 ? 1 : -1)) : -1;
     auto stamp = [&](int j, int k) {
@@ -575,8 +580,10 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
         const int64_t orow = active ? (int64_t)rb + p.b_off + ub : 0;
         const unsigned xrow = active ? (unsigned)xb_cur + (unsigned)ub : 0u;
         const unsigned prow = (active && j > 0) ? (unsigned)xb_prev + (unsigned)ub : 0u;
-        const unsigned xin = prow * 64u + (unsigned)kq * 16u;
-        const unsigned xout = xrow * 64u + (unsigned)kq * 16u;
+        unsigned xin = prow * 64u + (unsigned)kq * 16u;
+        unsigned xout = xrow * 64u + (unsigned)kq * 16u;
+        if (j > 0 && j <= tile_T && active) xin = ((unsigned)xb_prev + (unsigned)tile * 16u) * 64u + (unsigned)lane * 16u;
+        if (j < tile_T) xout = ((unsigned)xb_cur + (unsigned)tile * 16u) * 64u + (unsigned)lane * 16u;
         float4 pre4 = make_float4(0.f, 0.f, 0.f, 0.f), act4 = pre4;
         if (wave == 0 && active) {
             pre4 = *reinterpret_cast<const float4*>(pre + orow * ld + row0 + 4 * kq);
@@ -2055,7 +2062,7 @@ static int launch_recurrent_one(const RecArgs& a, const LaunchCtx& cx)
     }
     // 17..32 utterances, both chains of a direction in one 8-wave workgroup (round 4); variant 4 keeps
     // the two-workgroups-per-CU kernel of rounds 1-3
-    const int q8_variant = a.variant >= 8 ? a.variant : (a.variant == 0 ? REC_Q8_DEFAULT : 0);
+    const int q8_variant = (a.variant >= 8 && a.variant < 40) ? a.variant : (a.variant == 0 ? REC_Q8_DEFAULT : 0);   // 40..: A/B switches of other kernels
     if (ntiles == 2 && q8_variant >= 8) {
         RecKernel k8 = nullptr;
         switch (nwg) {

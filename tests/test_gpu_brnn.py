@@ -607,6 +607,41 @@ def test_async_entry_matches_sync(mods):
     assert net.regCostDev().item() == pytest.approx(net.regcost, rel=1e-6)   # engine: fp32 partial sums
 
 
+@pytest.mark.parametrize("H,B,equal", [(512, 24, False), (1824, 32, False), (1824, 32, True), (2048, 17, False)])
+def test_two_chain_recurrence_exchange_layout_is_bit_identical(mods, monkeypatch, H, B, equal):
+    """17..32 utterances (brnn_recurrent_q_kernel): a tile's KB of the exchange buffer is kept in lane order while all 16
+    utterances of the tile are alive and row-major for its last steps (round 5; a wave's load is one contiguous KB
+    instead of 16-byte pieces 64 bytes apart: 6.8 -> 6.3 us per step at the headline shape).  Every lane receives the
+    same values either way: costs and gradients are bit for bit those of SCTC_REC_VARIANT=46 (row-major throughout);
+    ragged lengths switch a tile from one layout to the other in mid-pass, B = 17 leaves the second tile incomplete"""
+    _, brnnet, obrnn, torch = mods
+    rs = np.random.RandomState(H + B)
+    D, A, NL, TL, Tmax = 24, 33, 3, 2, 14
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    Ts = [Tmax] * B if equal else [int(t) for t in rs.randint(1, Tmax + 1, size=B)]
+    Ts[3] = Tmax
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 5)).astype(np.int32) for T in Ts]
+    res = []
+    for variant in ("0", "46"):
+        monkeypatch.setenv("SCTC_REC_VARIANT", variant)
+        net = make_net(brnnet, (D, A, H, NL, TL, Tmax), params, maxUtts=B)
+        costs, _, skips = net.costAndGradBatch(datas, labs)
+        assert net.recurrentPath()[0] == 1
+        res.append((costs.copy(), skips.copy(), [net.grad[i][0].copy_to_host().copy() for i in range(NL + 3)]))
+        del net
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        np.testing.assert_array_equal(a, b)
+    if H <= 512:
+        with np.errstate(all="ignore"):
+            cr, gr, sr, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+        ok = ~sr
+        np.testing.assert_allclose(res[0][0][ok], cr[ok], rtol=1e-4)
+        assert rel(res[0][2][NL + 1], gr["Wf"]) < 2e-3
+
+
 @pytest.mark.parametrize("H,B", [(512, 52), (1824, 64), (2048, 100), (96, 90), (512, 128)])
 def test_large_minibatch_recurrence_pipelined_is_bit_identical(mods, monkeypatch, H, B):
     """more than 32 utterances (brnn_recurrent_kernel<NTW>): round 5 issues the exchange loads of batch k+1 under the
