@@ -634,6 +634,30 @@ def recurrent_by_minibatch(out, torch, cfg):
         del net, feats
         torch.cuda.empty_cache()
     out["roofline_recurrent"]["by_minibatch"] = res
+    # the whole cfg-3 step at 128 utterances of the full length (HBM-resident features): what the larger minibatch buys
+    # once the recurrence runs the units x utterances kernel (round 6) -- a side field, never `value`
+    B, T = 128, cfg["T"]
+    np.random.seed(0)
+    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B)
+    net.initParams()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    feats = torch.randn(B * T, D, device="cuda", generator=g)
+    rs = np.random.RandomState(9)
+    labels = [rs.randint(1, A, size=max(1, T // 10)).astype(np.int32) for _ in range(B)]
+    Ts = [T] * B
+    net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    out["minibatch_128"] = {"value": B * T / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "utterances": B, "T": T,
+                            "features": "HBM-resident", "recurrent_path": list(net.recurrentPath())}
+    del net, feats
+    torch.cuda.empty_cache()
 
 
 def ctc_saturation(out, torch, A, T, U):

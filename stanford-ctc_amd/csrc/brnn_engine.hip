@@ -1257,8 +1257,9 @@ int sctc_brnn_debug_buffer(sctc_brnn_t h, int32_t which, void** dev_ptr, int64_t
         if (which == 0) { c = h->Dp; l = LD(h->Dp); }
     } else if (which == 100) p = h->hF;
     else if (which == 101) p = h->hB;
+    else if (which == 102) p = h->Z;
     else if (which == 200) p = h->last_delta1;
-    SCTC_CHECK_ARG(p, "debug_buffer: no buffer %d (layers 0..%d, 100 hF, 101 hB, 200 delta_1)", which, h->NL);
+    SCTC_CHECK_ARG(p, "debug_buffer: no buffer %d (layers 0..%d, 100 hF, 101 hB, 102 z of the temporal layer, 200 delta_1)", which, h->NL);
     *dev_ptr = (void*)p;
     *rows = h->N;
     *cols = c;

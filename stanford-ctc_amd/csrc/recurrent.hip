@@ -43,6 +43,7 @@
 #include <fcntl.h>
 #include <string.h>
 #include <string>
+#include <type_traits>
 #include <sys/stat.h>
 #include <sys/file.h>
 #include <time.h>
@@ -648,6 +649,524 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
 }
 
 // ---------------------------------------------------------------------------------------
+// More than 32 utterances, tiled over UNITS x UTTERANCES (round 6).  brnn_recurrent_kernel above gives every
+// compute unit a 16 x H slab and the WHOLE minibatch: at 128 utterances every CU re-reads all 934 KB of the
+// direction's state from L2 each step (213 MB over the grid, 12.7 TB/s: that, not the matrix pipes, bounded
+// it at 0.54 of peak), and a step is one serial chain flags -> loads -> MFMAs -> stores -> flag.
+// Here a workgroup (one per CU) owns 32 units x HALF of the utterance tiles of one direction:
+//   * the same number of MFMAs per CU, half the state bytes per CU and step, no partial sums leaving the CU;
+//   * grid = 4 combos (direction, utterance half) x H/32 unit blocks (228 at H = 1824, 256 at H = 2048).  Blocks
+//     are dealt to XCDs round-robin (block b on XCD b % 8), combo = b & 3: a combo lives on two XCDs, whose L2s
+//     fetch one combo's state (a quarter of the exchange traffic of the grid) instead of everything;
+//   * the 32 x H slab (233 KB at H = 1824) is held partly in LDS, partly in registers (fragment order, as in
+//     the two-chain kernel), 4 waves = 4 K quarters, every x fragment is fetched ONCE per CU and multiplies both
+//     16-unit groups, every weight fragment multiplies all utterance tiles of the phase;
+//   * the CU's utterance tiles form TWO independent sub-chains (A, B) whose steps ("phases") alternate: while
+//     the results of A's step travel (store acknowledge, flag, fetch: three fabric trips, ~3.5 us), the CU
+//     multiplies B's step.  Nothing of a phase but its MFMAs is on the matrix pipes' critical path:
+//       - exchange loads run R - 1 batches ahead of the MFMAs through a ring of R register batches; the flags
+//         of the NEXT phase are polled, and its first R - 1 batches issued, from inside the current phase's MFMA
+//         stream (every wave polls for itself: no barrier in the stream);
+//       - the epilogue of a phase (K-quarter partial sums through LDS, clip / mask, the two stores, the flag)
+//         is executed in pieces BETWEEN the MFMAs of the next phase's first batch; the stores' acknowledge is
+//         awaited with a counted s_waitcnt behind that batch, each finishing wave publishes its own flag word
+//         (no publish barrier; a consumer lane reads the NC words of one producer).
+//     A sub-chain that runs alone (the other one finished, or fewer than 3 tiles in this half) has nothing to
+//     hide its latency behind: its epilogue is flushed at once and the next step starts cold.
+// The K split (base / rem quarters), the four accumulators per tile and the order of every addition are
+// those of the two-chain kernel brnn_recurrent_q_kernel: an utterance's rows are bit-identical to what it gets
+// in a minibatch of 17..32 (tools/rec_tiled_check.py).  Tile t of the (sorted) minibatch belongs to half t & 1,
+// sub-chain (t >> 1) & 1, slot t >> 2: all four chains of a direction get utterances of every length class.
+// NCQ: chunks per wave; NREGF: weight fragments (chunk, unit group) per wave kept in registers; NT: utterance
+// tiles per sub-chain (1: up to 64 utterances, 2: up to 128); NBAT batches per phase, ring of R (NBAT % R == 0).
+template <int... I, class F>
+__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, I...>, F&& f)
+{
+    (f(std::integral_constant<int, I>()), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_seq(std::make_integer_sequence<int, N>(), static_cast<F&&>(f));
+}
+
+template <int NCQ, int NREGF, int NT, int NBAT, int R, int PUB>
+__global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    constexpr int NFR = 2 * NCQ;             // weight fragments per wave: f = 2 * chunk + unit group
+    constexpr int NLDSF = NFR - NREGF;       // of them in LDS
+    constexpr int XB = (NCQ + NBAT - 1) / NBAT;   // chunks per batch
+    constexpr int NC = 2 * NT;               // results per phase: c = 2 * tile slot + unit group; wave c finishes c
+    static_assert(NC <= 4, "one result per wave");
+    static_assert(NBAT % R == 0 && NBAT >= 2 * R && R >= 2, "ring");
+    static_assert((NBAT - 1) * XB < NCQ, "no empty batch");
+    static_assert(PUB >= 0 && PUB < NBAT - R, "the flag is published before the next phase's flags are polled");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Hp = p.Hp, nch = Hp >> 4, nprod = Hp >> 5;
+    const int combo = blockIdx.x & 3, ublk = blockIdx.x >> 2;
+    const int g = combo & 1, half = combo >> 1;
+    const int row0 = ublk * 32;
+    const int uj = lane & 15, kq = lane >> 4;
+    const int sync_mode = p.sync_mode;
+    const int base = nch >> 2, rem = nch & 3;
+    const int cnt = base + (wave < rem ? 1 : 0);
+    const int c_beg = wave * base + min(wave, rem);
+    float4* Wl = lds4 + (size_t)wave * NLDSF * 64;     // [NLDSF][64] wave-private, fragment order
+    float4* red = lds4 + (size_t)4 * NLDSF * 64;       // [2 phase parities][NC][3 other waves][64] partial sums
+
+    auto load_w = [&](int c, int ug) {
+        const float* W = p.W[g];
+        const int r = row0 + 16 * ug + uj;
+        float4 v;
+        if (!p.transpose) {
+            v = *reinterpret_cast<const float4*>(W + (int64_t)r * p.ldw + 16 * c + 4 * kq);
+        } else {
+            const float* col = W + (int64_t)(16 * c + 4 * kq) * p.ldw + r;
+            v.x = col[0];
+            v.y = col[p.ldw];
+            v.z = col[2 * p.ldw];
+            v.w = col[3 * p.ldw];
+        }
+        return v;
+    };
+    // The register-resident fragments live in ACCUMULATION registers (an MFMA takes its A operand from either
+    // file): together with the exchange ring they would not fit the 256 architectural registers, and what the
+    // compiler then parks in the other file it copies back through a waited-for load -- the prefetch is gone.
+    float4 wreg[NREGF > 0 ? NREGF : 1];
+#pragma unroll
+    for (int f = 0; f < NREGF; ++f) {
+        const float4 w = load_w(c_beg + min(f >> 1, cnt - 1), f & 1);
+        asm("v_accvgpr_write_b32 %0, %1" : "=a"(wreg[f].x) : "v"(w.x));
+        asm("v_accvgpr_write_b32 %0, %1" : "=a"(wreg[f].y) : "v"(w.y));
+        asm("v_accvgpr_write_b32 %0, %1" : "=a"(wreg[f].z) : "v"(w.z));
+        asm("v_accvgpr_write_b32 %0, %1" : "=a"(wreg[f].w) : "v"(w.w));
+    }
+#pragma unroll 4
+    for (int f = NREGF; f < NFR; ++f) Wl[(f - NREGF) * 64 + lane] = load_w(c_beg + min(f >> 1, cnt - 1), f & 1);
+    __syncthreads();
+
+    const bool desc = p.descending[g] != 0;
+    const float* pre = p.pre[g];
+    const float* act = p.act[g];
+    const float* act_or_pre = act ? act : pre;
+    float* out = p.out[g];
+    const int64_t ld = p.ld;
+    const float hi = p.max_act > 0.f ? p.max_act : INFINITY;
+    unsigned* err = p.counters + 2;
+    const unsigned chunk_stride = (unsigned)p.n_xrows * 64u;
+    float* xg = p.xbuf + (size_t)g * p.n_xrows * Hp;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        xg, 0, (int)((size_t)p.n_xrows * Hp * sizeof(float)), 0x00020000);
+
+    struct Sub {
+        int ub[NT], uT[NT], tile_T[NT];
+        unsigned trow[NT];
+        int T;                  // steps of this sub-chain (its first tile's first utterance is its longest)
+        unsigned* flags;        // [nprod][REC_FLAG_STRIDE]: words 0..NC-1 of a producer = its finishing waves' step flags
+        int rb_next[NT];        // rowbase of the next step's frame (fetched one step ahead)
+        unsigned xb_next, xb_cur;
+    };
+    auto init_sub = [&](Sub& S, int sub) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int tile = (i * 2 + sub) * 2 + half;
+            S.trow[i] = (unsigned)tile * 16u;
+            S.ub[i] = tile * 16 + uj;
+            S.uT[i] = S.ub[i] < p.B ? p.T_b[S.ub[i]] : 0;
+            int m = 0x7fffffff;
+            for (int l = 0; l < 16; ++l) m = min(m, __builtin_amdgcn_readlane(S.uT[i], l));
+            S.tile_T[i] = p.variant == 46 ? 0 : m;
+            S.rb_next[i] = S.uT[i] > 0 ? p.rowbase[desc ? S.uT[i] - 1 : 0] : 0;
+        }
+        S.T = __builtin_amdgcn_readfirstlane((int)S.trow[0] < p.B ? p.T_b[S.trow[0]] : 0);
+        S.flags = p.counters + 32 + (size_t)((combo * 2 + sub) * 64) * REC_FLAG_STRIDE;
+        S.xb_next = (unsigned)p.xbase[0];
+        S.xb_cur = 0;
+    };
+    // xbase[j] is the same for every lane, which the compiler answers with a load and a v_readfirstlane waited for on
+    // the spot (vmcnt(0) at the head of every phase: the exchange ring drained).  An opaque zero in the index keeps
+    // the value in a vector register, first needed a phase later.
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    Sub A, Bc;
+    init_sub(A, 0);
+    init_sub(Bc, 1);
+
+    // diagnostics (SCTC_REC_DEBUG=1): wall-clock (100 MHz) stamps of steps 64..71 of both sub-chains, first and
+    // last unit block of combo 0: [wg][(step - 64) * 2 + sub][8]
+    // (kept in LDS and written out at the end: a store inside the time loop would change the counted waits)
+    const int dbg_sel = (p.debug && combo == 0 && tid == 0) ? (ublk == 0 ? 0 : (ublk == nprod - 1 ? 1 : -1)) : -1;
+    unsigned* dbg_lds = reinterpret_cast<unsigned*>(red + (size_t)2 * NC * 3 * 64);      // [16][8]
+    auto stamp = [&](int sub, int j, int k) {
+        if (dbg_sel >= 0 && j >= 64 && j < 72)
+            dbg_lds[((j - 64) * 2 + sub) * 8 + k] = (unsigned)wall_clock64();
+    };
+    // a stamp behind every chunk of steps 64..67: [(step - 64) * 2 + sub][32], written out behind the [512][8] region's head
+    unsigned* dbg_fine = dbg_lds + 16 * 8;
+    auto stamp_chunk = [&](int sub, int j, int c) {
+        if (dbg_sel >= 0 && j >= 64 && j < 68 && c < 32)
+            dbg_fine[((j - 64) * 2 + sub) * 32 + c] = (unsigned)wall_clock64();
+    };
+
+    float4 x[R][XB][NT];
+
+    // byte offsets (within a chunk) of the rows of step j - 1 that step j of sub-chain S multiplies
+    auto xin_of = [&](const Sub& S, int j, unsigned xb_prev, unsigned (&xin)[NT]) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const bool active = j < S.uT[i];
+            const unsigned prow = (active && j > 0) ? xb_prev + (unsigned)S.ub[i] : 0u;
+            xin[i] = prow * 64u + (unsigned)kq * 16u;
+            if (j > 0 && j <= S.tile_T[i] && active)       // the tile was complete at step j - 1: lane order
+                xin[i] = (xb_prev + S.trow[i]) * 64u + (unsigned)lane * 16u;
+        }
+    };
+    // batch bi of a phase into ring slot bi % R
+    auto issue_part = [&](const unsigned (&xin)[NT], auto bi_c, auto lo_c, auto hi_c) {
+        constexpr int bi = decltype(bi_c)::value, lo = decltype(lo_c)::value, hi_ = decltype(hi_c)::value;
+#pragma unroll
+        for (int u = lo; u < hi_; ++u) {
+            const int cu = bi * XB + u;
+            if (cu < NCQ) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    x[bi % R][u][i] = ld_x(xrsrc, xin[i], (unsigned)(c_beg + min(cu, cnt - 1)) * chunk_stride);
+            }
+        }
+    };
+    auto issue_batch = [&](const unsigned (&xin)[NT], auto bi_c) {
+        issue_part(xin, bi_c, std::integral_constant<int, 0>(), std::integral_constant<int, XB>());
+    };
+    // A lane reads the NC flag words of producer `lane` (lanes beyond the producers re-read the last one's): ONE ordinary
+    // 16-byte load, agent-coherent (sc1), unconditional -- an atomic load per word is waited for with vmcnt(0) on the
+    // spot, which would drain the exchange ring twice per phase.  The chain's step is the smallest word.
+    const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.counters, 0, (int)(REC_COUNTER_WORDS * sizeof(unsigned)), 0x00020000);
+    const unsigned flane = (unsigned)min(lane, nprod - 1) * (REC_FLAG_STRIDE * 4u);
+    auto flags_off = [&](const unsigned* fl) -> unsigned { return (unsigned)((fl - p.counters) * 4); };
+    auto poll_issue = [&](unsigned fl_off) -> u32x4 {
+        return __builtin_amdgcn_raw_buffer_load_b128(frsrc, flane, fl_off, 16 /* sc1 */);
+    };
+    auto poll_min = [&](const u32x4& v) -> unsigned {
+        unsigned f = v[0];
+#pragma unroll
+        for (int c = 1; c < NC; ++c) f = min(f, v[c]);
+        return f;
+    };
+    // every wave for itself: returns once all producers of the chain have published >= target
+    auto wait_flags = [&](unsigned fl_off, unsigned f, unsigned target) {
+        if (__all(f >= target)) return;
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+            __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");      // the flags change under us: load again
+            f = poll_min(poll_issue(fl_off));
+            if (__all(f >= target)) break;
+            if ((++spins & 255u) == 0) {
+                if (spin_expired(err, t0, lane)) break;
+            }
+        }
+    };
+    // cold start of a sub-chain's step j: flags of step j - 1, then the first R - 1 batches of its exchange loads
+    auto prologue = [&](const Sub& S, int j) {
+        first_poll_delay(p.poll_delay);
+        wait_flags(flags_off(S.flags), poll_min(poll_issue(flags_off(S.flags))), (unsigned)j);
+        unsigned xin[NT];
+        xin_of(S, j, S.xb_cur, xin);
+        static_for<R - 1>([&](auto b) { issue_batch(xin, b); });
+    };
+
+    // ---- the pending epilogue of a phase
+    struct Epi {
+        bool pending, zero;     // uniform: something to finish; step 0 (no partial sums)
+        bool lane_active;       // this lane's utterance is alive at that step (and this wave finishes a result)
+        int parity;             // which half of `red` holds the partial sums
+        f32x4 mine;
+        float4 pre4, act4, r0, r1, r2, s, o;
+        int64_t out_off;
+        unsigned xo, xchunk;
+        unsigned* flag;
+        unsigned val;
+    };
+    Epi E;
+    E.pending = false;
+    auto epi_barrier = [&](const Epi& e) {
+        if (e.pending && !e.zero) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    };
+    auto epi_read = [&](Epi& e) {
+        if (e.pending && !e.zero && wave < NC) {
+            const float4* r = red + (size_t)((e.parity * NC + wave) * 3) * 64 + lane;
+            e.r0 = r[0];
+            e.r1 = r[64];
+            e.r2 = r[128];
+        }
+    };
+    auto epi_sum = [&](Epi& e) {
+        e.s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e.pending && wave < NC && !e.zero) {
+            const float4 m = make_float4(e.mine[0], e.mine[1], e.mine[2], e.mine[3]);
+            // partial sums of waves 0..3 in that order, (p0 + p1) + (p2 + p3): the two-chain kernel's sum
+            float4 p0 = m, p1 = e.r0, p2 = e.r1, p3 = e.r2;
+            if (wave == 1) { p0 = e.r0; p1 = m; }
+            if (wave == 2) { p0 = e.r0; p1 = e.r1; p2 = m; }
+            if (wave == 3) { p0 = e.r0; p1 = e.r1; p2 = e.r2; p3 = m; }
+            e.s = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y),
+                              (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
+        }
+    };
+    auto epi_result = [&](Epi& e) {
+        if (e.pending && wave < NC) e.o = step_result(e.pre4, e.s, e.act4, act != nullptr, hi);
+    };
+    auto epi_stores = [&](const Epi& e) {
+        if (e.pending && wave < NC && e.lane_active) {
+            *reinterpret_cast<float4*>(out + e.out_off) = e.o;
+            st_x(xrsrc, e.xo, e.xchunk, e.o, sync_mode);
+        }
+    };
+    auto epi_store = [&](Epi& e) {
+        epi_sum(e);
+        epi_result(e);
+        epi_stores(e);
+    };
+    // n_after: exchange loads this wave has issued since epi_store (they stay in flight)
+    auto epi_publish = [&](Epi& e, auto n_after_c) {
+        constexpr int n_after = decltype(n_after_c)::value;
+        if (e.pending) {
+            if (wave < NC) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_after) : "memory");
+                if (lane == 0) {
+                    if (sync_mode == 0) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __hip_atomic_store(e.flag, e.val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            e.pending = false;
+        }
+    };
+    auto flush = [&](Epi& e) {
+        epi_barrier(e);
+        epi_read(e);
+        epi_store(e);
+        epi_publish(e, std::integral_constant<int, 0>());
+    };
+
+    int phase_no = 0;
+    // One step of sub-chain S.  j >= 1: on entry batches 0..R-2 of its exchange loads are in flight and `E` may
+    // hold the previous phase's epilogue, finished inside this phase's first batch.  If pre_next, the flags of N's
+    // step jn are polled and its first R - 1 batches issued from inside this phase's MFMA stream.  j == 0: no
+    // recurrent term.  On return E holds this phase's epilogue.
+    auto phase = [&](Sub& S, int sub, int j, bool pre_next, const Sub& N, int jn, auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;     // step 0, known at compile time: the time loop's copy has one path
+        stamp(sub, j, 0);
+        stamp_chunk(sub, j, 0);
+        const unsigned xb_prev = S.xb_cur, xb_cur = S.xb_next;
+        S.xb_cur = xb_cur;
+        int rb[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) rb[i] = S.rb_next[i];
+        // The loads whose results are needed LATER -- the next step's xbase / rowbase, this step's additive term (its
+        // epilogue runs inside the next phase) -- are issued behind the first batches, not here: anything loaded at the
+        // head of the phase ends up being waited for inside batch 0 together with the exchange ring.
+        auto late_loads = [&](Epi& en) {
+            const int jn2 = min(j + 1, S.T - 1);
+            S.xb_next = (unsigned)p.xbase[jn2 + vzero];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int tn = desc ? S.uT[i] - 1 - jn2 : jn2;
+                S.rb_next[i] = p.rowbase[min(max(tn, 0), p.Tmax - 1)];
+            }
+            // unconditional (an idle lane's out_off is 0; without a mask matrix the additive term is read twice): a load
+            // under a branch meets its zero default in a copy, and the copy waits with vmcnt(0)
+            en.pre4 = *reinterpret_cast<const float4*>(pre + en.out_off);
+            en.act4 = *reinterpret_cast<const float4*>(act_or_pre + en.out_off);
+        };
+        unsigned xin[NT];
+        xin_of(S, j, xb_prev, xin);
+        // what this wave's epilogue needs (result c = wave: tile slot c >> 1, unit group c & 1)
+        Epi En;
+        En.pending = true;
+        En.zero = FIRST;
+        En.parity = phase_no & 1;
+        En.lane_active = false;
+        En.out_off = 0;
+        En.xo = 0;
+        En.xchunk = (unsigned)(2 * ublk + (wave & 1)) * chunk_stride;
+        En.flag = S.flags + ublk * REC_FLAG_STRIDE + wave;
+        En.val = (unsigned)(j + 1);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if ((wave >> 1) == i && wave < NC) {
+                const bool active = j < S.uT[i];
+                const int64_t orow = active ? (int64_t)rb[i] + p.b_off + S.ub[i] : 0;
+                const unsigned xrow = active ? xb_cur + (unsigned)S.ub[i] : 0u;
+                En.xo = xrow * 64u + (unsigned)kq * 16u;
+                if (j < S.tile_T[i]) En.xo = (xb_cur + S.trow[i]) * 64u + (unsigned)lane * 16u;
+                En.lane_active = active;
+                En.out_off = orow * ld + row0 + 16 * (wave & 1) + 4 * kq;
+            }
+        }
+        if constexpr (FIRST) late_loads(En);
+        f32x4 acc[2][NT][4];
+#pragma unroll
+        for (int ug = 0; ug < 2; ++ug)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[ug][i][q] = {0.f, 0.f, 0.f, 0.f};
+
+        // four MFMAs: chunk u of batch bi, result g = 2 * tile slot + unit group
+        auto mfma_group = [&](auto bi_c, auto u_c, auto g_c) {
+            constexpr int bi = decltype(bi_c)::value, u = decltype(u_c)::value, cu = bi * XB + u;
+            constexpr int gi = decltype(g_c)::value >> 1, ug = decltype(g_c)::value & 1;
+            if constexpr (cu < NCQ) {
+                if (cu < NCQ - 1 || cnt == NCQ) {     // the last chunk exists only in the longer waves
+                    constexpr int f = 2 * cu + ug;
+                    float4 a;
+                    if constexpr (f < NREGF) a = wreg[f]; else a = Wl[(f - NREGF) * 64 + lane];
+                    SCTC_MFMA4(acc[ug][gi], a, x[bi % R][u][gi])
+                }
+            }
+        };
+        auto mfma_chunk = [&](auto bi_c, auto u_c) {
+            static_for<NC>([&](auto g_c) { mfma_group(bi_c, u_c, g_c); });
+        };
+        if constexpr (!FIRST) {
+            // the next phase's poll and first batches are issued unconditionally (without a next phase: this chain's
+            // own flags, exchange row 0, results unused) -- a load under a branch makes every later wait a vmcnt(0)
+            const unsigned nfl_off = flags_off(N.flags);
+            u32x4 fl = {0u, 0u, 0u, 0u};
+            unsigned xin_n[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) xin_n[i] = (unsigned)kq * 16u;
+            // ONE exchange load behind a group of four MFMAs (128 cycles of the matrix pipe), never a batch at once: the CU's
+            // one vector-memory path takes a KB (a wave's 16-byte-per-lane load) every 16 cycles, so ten loads from each of
+            // the four waves keep it busy for 640 cycles, and a wave whose load does not issue does not issue MFMAs either
+            // (measured: +0.3 us per batch issued in one go).
+            auto issue_one = [&](const unsigned (&xs)[NT], auto bi_c, auto l_c) {
+                constexpr int bi = decltype(bi_c)::value, l = decltype(l_c)::value, u = l / NT, i = l % NT, cu = bi * XB + u;
+                if constexpr (cu < NCQ)
+                    x[bi % R][u][i] = ld_x(xrsrc, xs[i], (unsigned)(c_beg + min(cu, cnt - 1)) * chunk_stride);
+            };
+            static_for<NBAT>([&](auto b_c) {
+                constexpr int b = decltype(b_c)::value;
+                constexpr int nb = b + R - 1;       // the batch whose loads are issued between batch b's MFMAs
+                constexpr int XBb = (b + 1) * XB <= NCQ ? XB : NCQ - b * XB, NG = XBb * NC;      // chunks, groups of this batch
+                constexpr int NL = XB * NT;                                                    // load slots of a batch
+                // batch 0: the previous phase's epilogue in pieces behind groups NC-1 .., then the loads, one per group;
+                // other batches: a load behind every second group
+#define SCTC_T_SLOT(piece) (NC - 1 + (piece) < NG - 1 ? NC - 1 + (piece) : NG - 1)
+                if constexpr (b == NBAT - R) {
+                    fl = poll_issue(nfl_off);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (b == NBAT - R + 1) {
+                    if (pre_next) {
+                        wait_flags(nfl_off, poll_min(fl), (unsigned)jn);
+                        xin_of(N, jn, N.xb_cur, xin_n);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                static_for<NG>([&](auto s_c) {
+                    constexpr int s = decltype(s_c)::value;
+                    mfma_group(b_c, std::integral_constant<int, s / NC>(), std::integral_constant<int, s % NC>());
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (s % NC == NC - 1) stamp_chunk(sub, j, 1 + b * XB + s / NC);
+                    if constexpr (b == 0) {
+                        if constexpr (s % NC == NC - 1 && s / NC < 5) stamp(sub, j, 1 + s / NC);
+                        if constexpr (s == SCTC_T_SLOT(0)) { epi_barrier(E); __builtin_amdgcn_sched_barrier(0); }
+                        if constexpr (s == SCTC_T_SLOT(1)) { epi_read(E); __builtin_amdgcn_sched_barrier(0); }
+                        if constexpr (s == SCTC_T_SLOT(2)) { epi_sum(E); __builtin_amdgcn_sched_barrier(0); }
+                        if constexpr (s == SCTC_T_SLOT(3)) { epi_result(E); __builtin_amdgcn_sched_barrier(0); }
+                        if constexpr (s == SCTC_T_SLOT(4)) { epi_stores(E); __builtin_amdgcn_sched_barrier(0); }
+                    }
+                    static_for<NL>([&](auto l_c) {
+                        constexpr int l = decltype(l_c)::value, raw = b == 0 ? SCTC_T_SLOT(5) + l : l * NG / NL;
+                        if constexpr ((raw < NG - 1 ? raw : NG - 1) == s) {
+                            if constexpr (nb < NBAT) issue_one(xin, std::integral_constant<int, nb>(), l_c);
+                            else issue_one(xin_n, std::integral_constant<int, nb - NBAT>(), l_c);
+                        }
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if constexpr (b == NBAT - 1) {
+                    // The late loads get a use here: left alone the compiler sinks them to the loop latch, next to the
+                    // copies that swap the sub-chains, and waits for them there with vmcnt(0) -- the ring drained.
+                    asm volatile("" : "+v"(S.xb_next));
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) asm volatile("" : "+v"(S.rb_next[i]));
+                    asm volatile("" : "+v"(En.pre4.x), "+v"(En.pre4.y), "+v"(En.pre4.z), "+v"(En.pre4.w));
+                    asm volatile("" : "+v"(En.act4.x), "+v"(En.act4.y), "+v"(En.act4.z), "+v"(En.act4.w));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (b == PUB) {
+                    // exchange loads issued since the epilogue's stores: batches R-1 .. R-1+PUB of this phase
+                    constexpr int first = (R - 1) * XB, end = (R + PUB) * XB < NCQ ? (R + PUB) * XB : NCQ;
+                    epi_publish(E, std::integral_constant<int, NT * (end - first)>());
+                    __builtin_amdgcn_sched_barrier(0);
+                    late_loads(En);
+                    __builtin_amdgcn_sched_barrier(0);
+                    stamp(sub, j, 6);
+                }
+            });
+            stamp(sub, j, 7);
+            // K quarters: wave c keeps its own partial sum of result c, the others park theirs in LDS
+            float4* rp = red + (size_t)(En.parity * NC * 3) * 64 + lane;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x4 s = (acc[c & 1][c >> 1][0] + acc[c & 1][c >> 1][1]) + (acc[c & 1][c >> 1][2] + acc[c & 1][c >> 1][3]);
+                if (wave == c) En.mine = s;
+                else rp[(c * 3 + (wave < c ? wave : wave - 1)) * 64] = make_float4(s[0], s[1], s[2], s[3]);
+            }
+        } else {
+            En.mine = {0.f, 0.f, 0.f, 0.f};
+        }
+        E = En;
+        ++phase_no;
+    };
+
+    // step 0 of both sub-chains (no recurrent term), then A and B alternate while B lasts (T_A >= T_B: the
+    // minibatch is sorted), then A alone with its exchange latency exposed.  ONE copy of the phase body: `cur` and
+    // `nxt` swap places after a phase that has started the other chain's loads (two inlined copies get two register
+    // assignments for the exchange ring, and the copies between them wait for loads that are still in flight).
+    if (A.T > 0) { phase(A, 0, 0, false, A, 0, std::true_type()); flush(E); }
+    if (Bc.T > 0) { phase(Bc, 1, 0, false, Bc, 0, std::true_type()); flush(E); }
+    Sub cur = A, nxt = Bc;
+    int jc = 1, jn = 1, subc = 0;
+    if (jc < cur.T) prologue(cur, jc);
+    while (jc < cur.T) {
+        const bool pre_next = jn < nxt.T;
+        phase(cur, subc, jc, pre_next, nxt, jn, std::false_type());
+        ++jc;
+        if (pre_next) {
+            const Sub t = cur;
+            cur = nxt;
+            nxt = t;
+            const int tj = jc;
+            jc = jn;
+            jn = tj;
+            subc ^= 1;
+        } else {
+            flush(E);
+            if (jc < cur.T) prologue(cur, jc);
+        }
+    }
+    if (dbg_sel >= 0) {
+        for (int i = 0; i < 16 * 8; ++i) p.debug[dbg_sel * 16 * 8 + i] = dbg_lds[i];
+        for (int i = 0; i < 8 * 32; ++i) p.debug[REC_DEBUG_ALL_OFF + dbg_sel * 8 * 32 + i] = dbg_fine[i];
+    }
+}
+
+#ifdef SCTC_REC_EXPERIMENTS    // measured slower / superseded kernels, kept for the A/Bs of profiles/r04_recurrence_q8.md and r05 (build with -DSCTC_REC_EXPERIMENTS)
+// ---------------------------------------------------------------------------------------
 // Both chains of a direction in ONE workgroup (17..32 utterances; round 4).  The two-chain kernel
 // above leaves the pairing of chains on a compute unit to the dispatcher: 200 CUs hold two
 // workgroups, 56 hold one, the workgroups that share need 5.1 us from "flags seen" to "published"
@@ -942,6 +1461,8 @@ __global__ __launch_bounds__(512, 1) void brnn_recurrent_q8_kernel(RecArgs p)
     }
 }
 
+#endif  // SCTC_REC_EXPERIMENTS
+
 // ---------------------------------------------------------------------------------------
 // Small-batch variant (1..4 utterances: the reference's minibatch-1 mode).  With one utterance
 // a step is a 16 x H matrix-vector product per workgroup (0.1 us of VALU work) and the whole
@@ -1131,6 +1652,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
     }
 }
 
+#ifdef SCTC_REC_EXPERIMENTS    // superseded at 6..16 utterances by the single-chain flag kernel (round 5); SCTC_REC_VARIANT=42
 // ---------------------------------------------------------------------------------------
 // Mid-batch variant (6..16 utterances): the one-hop sentinel exchange of the small-batch kernel
 // with the matrix cores of the big ones.  A workgroup owns 16 output units; its 16 x H weight
@@ -1274,6 +1796,8 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_m_kernel(RecArgs p)
     }
 }
 
+
+#endif  // SCTC_REC_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------
 // 16-bit-operand variant of the mid-batch kernel for the "fp16 activations" configuration
@@ -2045,6 +2569,7 @@ static int launch_recurrent_one(const RecArgs& a, const LaunchCtx& cx)
             if (done) return SCTC_OK;
         }
     }
+#ifdef SCTC_REC_EXPERIMENTS
     if (a.B > 5 && a.B <= 16 && a.variant != 1) {
         RecKernel mk = nullptr;
         switch ((nwg + 3) / 4) {
@@ -2060,6 +2585,8 @@ static int launch_recurrent_one(const RecArgs& a, const LaunchCtx& cx)
             if (done) return SCTC_OK;
         }
     }
+#endif
+#ifdef SCTC_REC_EXPERIMENTS
     // 17..32 utterances, both chains of a direction in one 8-wave workgroup (round 4); variant 4 keeps
     // the two-workgroups-per-CU kernel of rounds 1-3
     const int q8_variant = (a.variant >= 8 && a.variant < 40) ? a.variant : (a.variant == 0 ? REC_Q8_DEFAULT : 0);   // 40..: A/B switches of other kernels
@@ -2081,6 +2608,7 @@ static int launch_recurrent_one(const RecArgs& a, const LaunchCtx& cx)
             if (done) return SCTC_OK;
         }
     }
+#endif
     if (ntiles == 2 && a.variant != 1 && 4 * nwg <= 2 * cx.cus && (4 * nwg) % 8 == 0) {
         // two chains per CU; NREG keeps the LDS share of the slab at <= 76 KiB per workgroup
         RecKernel qk = nullptr;
@@ -2096,6 +2624,36 @@ static int launch_recurrent_one(const RecArgs& a, const LaunchCtx& cx)
             const size_t smem = sizeof(float4) * ((size_t)4 * (ncq - nreg) * 64 + 3 * 64);
             SCTC_TRY(launch_persistent(qk, 4 * nwg, smem, 2, 0, a, cx, &done));
             if (done) return SCTC_OK;     // otherwise: the one-workgroup-per-CU kernel below
+        }
+    }
+    // 33..128 utterances: 32 units x half the utterance tiles per CU, two alternating sub-chains (round 6);
+    // variants 1 / 40 / 47 keep the one-slab-per-CU kernel below
+    if (ntiles > 2 && a.variant != 1 && a.variant != 40 && a.variant != 47 && 4 * (a.Hp / 32) <= cx.cus) {
+        RecKernel tk = nullptr;
+        const bool one = ntiles <= 4;       // one utterance tile per sub-chain
+        int nldsf = 0;
+        // <chunks per wave, weight fragments in registers, tiles per sub-chain, batches per phase, ring depth, publish batch>;
+        // SCTC_REC_TCFG=1: six batches, ring of three (A/B of the schedule, tools/rec_tiled_sweep.sh: equal within the noise)
+        static const int tcfg = getenv("SCTC_REC_TCFG") ? atoi(getenv("SCTC_REC_TCFG")) : 0;
+        switch (nwg) {
+            case 32:  tk = one ? brnn_recurrent_t_kernel<8, 0, 1, 4, 2, 0>  : brnn_recurrent_t_kernel<8, 0, 2, 4, 2, 0>;  nldsf = 16; break;  // H = 512
+            case 64:  tk = one ? brnn_recurrent_t_kernel<16, 0, 1, 4, 2, 1> : brnn_recurrent_t_kernel<16, 0, 2, 4, 2, 1>; nldsf = 32; break;  // H = 1024
+            case 114:   // H = 1824
+                nldsf = 33;
+                if (one) tk = tcfg == 1 ? brnn_recurrent_t_kernel<29, 25, 1, 6, 3, 1> : brnn_recurrent_t_kernel<29, 25, 1, 8, 4, 1>;
+                else tk = tcfg == 1 ? brnn_recurrent_t_kernel<29, 25, 2, 6, 3, 1> : brnn_recurrent_t_kernel<29, 25, 2, 8, 4, 1>;
+                break;
+            case 128:   // H = 2048
+                nldsf = 33;
+                if (one) tk = tcfg == 1 ? brnn_recurrent_t_kernel<32, 31, 1, 6, 3, 1> : brnn_recurrent_t_kernel<32, 31, 1, 8, 4, 1>;
+                else tk = tcfg == 1 ? brnn_recurrent_t_kernel<32, 31, 2, 6, 3, 1> : brnn_recurrent_t_kernel<32, 31, 2, 8, 4, 1>;
+                break;
+            default: break;
+        }
+        if (tk) {
+            const size_t smem = sizeof(float4) * 64 * ((size_t)4 * nldsf + 2 * 3 * (one ? 2 : 4)) + (16 * 8 + 8 * 32) * sizeof(unsigned);
+            SCTC_TRY(launch_persistent(tk, 4 * (a.Hp / 32), smem, 1, 0, a, cx, &done));
+            if (done) return SCTC_OK;
         }
     }
     const int ntw = ntiles <= 2 ? 1 : (ntiles <= 4 ? 2 : 4);
@@ -2140,13 +2698,19 @@ int launch_recurrent(const RecArgs& a_in, hipStream_t stream, int* path)
     constexpr int MAXB = 128;
     for (int b0 = 0; b0 < a_in.B;) {
         int nb = std::min(MAXB, a_in.B - b0);
-        // 33..48 utterances: the two-chain kernel on the first 32 (6.8 us per step) and the single-chain kernel on the
-        // rest (4.6-5.0, and only as many steps as ITS longest utterance has) beat the one-workgroup-per-CU kernel on all
-        // of them (12.2 / 13.0 us per step at 40 / 48; round 5, tools/rec_large_bench.py); variant 45 keeps one launch
-        if (nb > 32 && nb <= 48 && a.variant == 0 && !a.prec16) nb = 32;
-        // likewise 65..80: the four-tiles-per-wave kernel costs the same 21 us per step for 65 utterances as for 128
-        // (its tiles are all multiplied), 64 on the two-tile kernel (12.8) + up to 16 on the single-chain kernel (<= 5.0) less
-        else if (nb > 64 && nb <= 80 && a.variant == 0 && !a.prec16) nb = 64;
+        // How a minibatch is cut into launches (utterances are independent, sorted by length: a later launch covers only as
+        // many steps as ITS longest utterance has).  Round 6, with the units x utterances kernel (tools/rec_tiled_sweep.sh,
+        // H = 1824, us per time step, equal lengths): 33..64 utterances in ONE launch (40 / 48: 10.5 against 11.2 / 11.7 for
+        // 32 + the rest, round 5's cut); 65..96 as 64 + the rest (72 / 80: 15.0 against 18.7 in one launch of the two-tile
+        // form, which multiplies its empty tile slots; 96 = 64 + 32: 9.5 + 6.4); 97..128 in one launch (18.7).
+        // Variant 45: never cut.  Kernels without the tiled form (variants 1 / 40 / 47, other layer sizes) keep round 5's cuts.
+        const bool tiled = a.variant == 0 && !a.prec16 && (a.Hp == 512 || a.Hp == 1024 || a.Hp == 1824 || a.Hp == 2048) && 4 * (a.Hp / 32) <= cx.cus;
+        if (tiled) {
+            if (nb > 64 && nb <= 96) nb = 64;
+        } else {
+            if (nb > 32 && nb <= 48 && a.variant == 0 && !a.prec16) nb = 32;
+            else if (nb > 64 && nb <= 80 && a.variant == 0 && !a.prec16) nb = 64;
+        }
         RecArgs c = a;
         c.b_off = a_in.b_off + b0;
         c.T_b = a_in.T_b + b0;

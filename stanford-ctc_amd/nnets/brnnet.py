@@ -377,7 +377,7 @@ class NNet:
 
     def debugBuffer(self, which):
         """diagnostics: host copy (float64, [rows][cols]) of an internal matrix of the last call --
-        which: 0..numLayers = hActs[i], 100 / 101 = hActsFor / hActsBack, 200 = delta entering layer 1"""
+        which: 0..numLayers = hActs[i], 100 / 101 = hActsFor / hActsBack, 102 = the temporal layer's W h + b, 200 = delta entering layer 1"""
         torch = _sctc.require_gpu()
         ptr, rows, cols, ld = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         _sctc.check(_sctc.lib().sctc_brnn_debug_buffer(self._h, which, ctypes.byref(ptr), ctypes.byref(rows),

@@ -10,6 +10,8 @@ stated tolerance in tests/test_gpu_fullsize.py.
 import io
 import pickle
 
+import os
+
 import numpy as np
 import pytest
 
@@ -470,13 +472,14 @@ def test_recurrent_small_batch_kernel_layer_sizes(mods, monkeypatch, H):
     assert costs[1] == pytest.approx(c_ref, rel=1e-4)
 
 
-@pytest.mark.parametrize("variant", ["0", "42"])
 @pytest.mark.parametrize("H,B", [(512, 6), (512, 16), (1824, 9), (2048, 12), (1024, 7), (1824, 16)])
-def test_recurrent_mid_batch_kernel(mods, monkeypatch, H, B, variant):
+def test_recurrent_mid_batch_kernel(mods, monkeypatch, H, B):
     """6..16 utterances (4..16 since the crossover measurement): since round 5 the flag kernel with ONE chain per
-    direction (brnn_recurrent_q_kernel on half its grid; variant 0), before that the sentinel-exchange MFMA kernel
-    (brnn_recurrent_m_kernel; variant 42): ragged minibatch against the one-workgroup-per-CU flag kernel
-    (SCTC_REC_VARIANT=1) and, at H=512, the oracle; the two agree bit for bit"""
+    direction (brnn_recurrent_q_kernel on half its grid).  Ragged minibatch against the one-workgroup-per-CU flag
+    kernel (SCTC_REC_VARIANT=1) and, at H=512, the oracle.  (The sentinel-exchange MFMA kernel it replaced,
+    brnn_recurrent_m_kernel / variant 42, agreed bit for bit in round 5 and is compiled only with
+    -DSCTC_REC_EXPERIMENTS since round 6.)"""
+    variant = "0"
     _, brnnet, obrnn, _ = mods
     rs = np.random.RandomState(31 * H + B)
     D, A, NL, TL = 32, 33, 2, 1
@@ -506,13 +509,6 @@ def test_recurrent_mid_batch_kernel(mods, monkeypatch, H, B, variant):
     np.testing.assert_allclose(costs[~skips], costs1[~skips], rtol=1e-5)
     for a, b in zip(g_m, _all_grads(net1, NL)):
         assert rel(a, b) < 1e-4
-    if variant == "0":
-        monkeypatch.setenv("SCTC_REC_VARIANT", "42")
-        net2 = make_net(brnnet, (D, A, H, NL, TL, max(Ts)), params, maxUtts=B)
-        costs2, _, _ = net2.costAndGradBatch(datas, labs)
-        np.testing.assert_array_equal(costs, costs2)
-        for a, b in zip(g_m, _all_grads(net2, NL)):
-            np.testing.assert_array_equal(a, b)
 
 
 @pytest.mark.parametrize("H,B", [(64, 40), (512, 48), (512, 70)])
@@ -644,12 +640,15 @@ def test_two_chain_recurrence_exchange_layout_is_bit_identical(mods, monkeypatch
 
 @pytest.mark.parametrize("H,B", [(512, 52), (1824, 64), (2048, 100), (96, 90), (512, 128)])
 def test_large_minibatch_recurrence_pipelined_is_bit_identical(mods, monkeypatch, H, B):
-    """more than 32 utterances (brnn_recurrent_kernel<NTW>): round 5 issues the exchange loads of batch k+1 under the
-    MFMAs of batch k; the same MFMAs on the same accumulators in the same order, so costs and every gradient are
-    bit for bit what SCTC_REC_VARIANT=40 (loads, fence, MFMAs: rounds 1-4) gives; ragged lengths, both passes.
-    Likewise the exchange layout: a tile of 16 utterances is kept [k quarter][utterance][4 units] (a wave reads one
-    contiguous KB) while all 16 are alive and row-major for its last steps -- the ragged lengths here switch every
-    tile from one to the other; SCTC_REC_VARIANT=46 keeps row-major throughout: same numbers"""
+    """more than 32 utterances on the one-slab-per-CU kernel (brnn_recurrent_kernel<NTW>; the default up to round 5, since
+    round 6 SCTC_REC_VARIANT=47 and every layer size without the tiled form): round 5 issues the exchange loads of batch
+    k+1 under the MFMAs of batch k; the same MFMAs on the same accumulators in the same order, so costs and every gradient
+    are bit for bit what SCTC_REC_VARIANT=40 (loads, fence, MFMAs: rounds 1-4) gives; ragged lengths, both passes.
+    The exchange layout: a tile of 16 utterances is kept [k quarter][utterance][4 units] (a wave reads one contiguous KB)
+    while all 16 are alive and row-major for its last steps -- the ragged lengths here switch every tile from one to the
+    other; SCTC_REC_VARIANT=46 keeps row-major throughout in whatever kernel the default is: same numbers as the default.
+    Default (round 6: the units x utterances kernel where the layer size has one) against variant 47: another K split,
+    so close, not equal."""
     _, brnnet, obrnn, torch = mods
     rs = np.random.RandomState(H + B)
     D, A, NL, TL, Tmax = 24, 33, 3, 2, 14
@@ -659,18 +658,23 @@ def test_large_minibatch_recurrence_pipelined_is_bit_identical(mods, monkeypatch
     datas = [rs.randn(D, T) for T in Ts]
     labs = [rs.randint(1, A, size=max(1, T // 5)).astype(np.int32) for T in Ts]
     res = []
-    for variant in ("0", "40", "46"):
+    for variant in ("0", "46", "47", "40"):
         monkeypatch.setenv("SCTC_REC_VARIANT", variant)
         net = make_net(brnnet, (D, A, H, NL, TL, Tmax), params, maxUtts=B)
         costs, _, skips = net.costAndGradBatch(datas, labs)
         assert net.recurrentPath()[0] == 1
         res.append((costs.copy(), skips.copy(), [net.grad[i][0].copy_to_host().copy() for i in range(NL + 3)]))
         del net
-    for other in res[1:]:
-        np.testing.assert_array_equal(res[0][0], other[0])
-        np.testing.assert_array_equal(res[0][1], other[1])
-        for a, b in zip(res[0][2], other[2]):
+    for first, other in ((res[0], res[1]), (res[2], res[3])):
+        np.testing.assert_array_equal(first[0], other[0])
+        np.testing.assert_array_equal(first[1], other[1])
+        for a, b in zip(first[2], other[2]):
             np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(res[0][1], res[2][1])
+    ok = ~res[0][1]
+    np.testing.assert_allclose(res[0][0][ok], res[2][0][ok], rtol=1e-5)
+    for a, b in zip(res[0][2], res[2][2]):
+        assert rel(a, b) < 1e-3
     if H <= 512:
         with np.errstate(all="ignore"):
             cr, gr, sr, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
@@ -718,12 +722,11 @@ def test_recurrent_small_batch_crossover(mods, monkeypatch, H, B):
         np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("H,B", [(512, 33), (512, 40), (1824, 48), (512, 66), (1824, 80)])
+@pytest.mark.parametrize("H,B", [(512, 33), (512, 40), (1824, 48), (512, 66), (1824, 80), (96, 40), (96, 70), (1024, 96)])
 def test_recurrence_33_to_48_utterances_as_two_launches(mods, monkeypatch, H, B):
-    """33..48 utterances run as the two-chain kernel on the first 32 plus the single-chain (or, for 1..3 left over, the
-    VALU) kernel on the rest since round 5 (8.97 / 11.4 / 12.2 us per step at 33 / 40 / 48 against 12.3 / 12.2 / 12.6 for
-    one launch of the one-workgroup-per-CU kernel, SCTC_REC_VARIANT=45), 65..80 as 64 + the rest (15.2 / 17.7 us at
-    65 / 80 against 20.0 / 20.3): ragged lengths against that single launch and, at H=512, the oracle"""
+    """Minibatches cut into several launches (round 5: 33..48 as 32 + the rest, 65..80 as 64 + the rest; round 6, where the
+    layer size has the units x utterances kernel: 33..64 in one launch, 65..96 as 64 + the rest -- recurrent.hip
+    launch_recurrent): ragged lengths against a single launch (SCTC_REC_VARIANT=45) and, at H=512, the oracle"""
     _, brnnet, obrnn, _ = mods
     rs = np.random.RandomState(3 * H + B)
     D, A, NL, TL, Tmax = 24, 33, 3, 2, 18
@@ -751,3 +754,94 @@ def test_recurrence_33_to_48_utterances_as_two_launches(mods, monkeypatch, H, B)
     np.testing.assert_allclose(res[0][0][ok], res[1][0][ok], rtol=1e-5)
     for a, b in zip(res[0][2], res[1][2]):
         assert rel(a, b) < 1e-3
+
+
+def _note(text):      # observed numbers also go to gpurun_out/test_notes.txt (pytest swallows stdout)
+    print(text)
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "test_notes.txt"), "a") as f:
+            f.write(text + "\n")
+    except OSError:
+        pass
+
+
+def _packed_rowbase(Ts):
+    Ts = np.asarray(Ts)
+    alive = np.array([(Ts > t).sum() for t in range(Ts.max())])
+    return np.concatenate([[0], np.cumsum(alive)[:-1]])
+
+
+@pytest.mark.parametrize("H,B,ragged", [(512, 33, True), (512, 64, False), (1024, 100, True), (1824, 64, True), (1824, 128, True),
+                                        (2048, 128, False), (1824, 50, True), (512, 128, True)])
+def test_tiled_recurrence_rows_equal_minibatches_of_32(mods, monkeypatch, H, B, ragged):
+    """more than 32 utterances, round 6: brnn_recurrent_t_kernel (32 units x half the utterance tiles per CU, two
+    alternating sub-chains, exchange loads in a register ring, the epilogue of a phase between the next phase's MFMAs)
+    keeps the K split and the order of every addition of the two-chain kernel of 17..32 utterances, so the rows of
+    hActsFor / hActsBack of an utterance are BIT-identical to what it gets in a minibatch of 32 (sorted order; the last,
+    partial group of 1..16 runs other kernels and is left out); the whole step against the one-slab-per-CU kernel
+    (SCTC_REC_VARIANT=47: another K split) and, at H=512, the oracle; run-to-run reproducible"""
+    _, brnnet, obrnn, torch = mods
+    rs = np.random.RandomState(5 * H + B)
+    D, A, NL, TL, Tmax = 24, 33, 3, 2, 22
+    Tmin = 2
+    if H > 1024:        # enough frames that the GEMM in front of the recurrence runs without a K split in both minibatches
+        Tmax, Tmin = 480, 455
+    params = obrnn.init_params(D, A, H, NL, TL, rng=rs)
+    Ts = sorted([int(t) for t in (rs.randint(Tmin, Tmax + 1, size=B) if ragged else [Tmax] * B)], reverse=True)
+    Ts[0] = Tmax
+    datas = [rs.randn(D, T) for T in Ts]
+    labs = [rs.randint(1, A, size=max(1, T // 5)).astype(np.int32) for T in Ts]
+    monkeypatch.setenv("SCTC_REC_VARIANT", "0")
+    net = make_net(brnnet, (D, A, H, NL, TL, Tmax), params, maxUtts=B)
+    costs, _, skips = net.costAndGradBatch(datas, labs)
+    assert net.recurrentPath()[:2] == (1, 1)
+    hF, hB, Z = net.debugBuffer(100), net.debugBuffer(101), net.debugBuffer(102)
+    g_t = _all_grads(net, NL)
+    net.costAndGradBatch(datas, labs)
+    for a, b in zip(g_t, _all_grads(net, NL)):
+        np.testing.assert_array_equal(a, b)
+    if H == 512:
+        with np.errstate(all="ignore"):
+            cr, gr, sr, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+        np.testing.assert_array_equal(skips, sr)
+        np.testing.assert_allclose(costs[~sr], cr[~sr], rtol=1e-4)
+        check_grads(net, gr, NL, tol=1e-3)
+    del net
+    monkeypatch.setenv("SCTC_REC_VARIANT", "47")
+    net1 = make_net(brnnet, (D, A, H, NL, TL, Tmax), params, maxUtts=B)
+    costs1, _, skips1 = net1.costAndGradBatch(datas, labs)
+    np.testing.assert_array_equal(skips, skips1)
+    np.testing.assert_allclose(costs[~skips], costs1[~skips], rtol=1e-5)
+    for a, b in zip(g_t, _all_grads(net1, NL)):
+        assert rel(a, b) < 1e-3
+    del net1
+    monkeypatch.setenv("SCTC_REC_VARIANT", "0")
+    rb = _packed_rowbase(Ts)
+    n_equal = n_seen = 0
+    for b0 in range(0, B, 32):
+        b1 = min(b0 + 32, B)
+        if b1 - b0 <= 16:
+            continue
+        sub = make_net(brnnet, (D, A, H, NL, TL, Tmax), params, maxUtts=b1 - b0)
+        sub.costAndGradBatch(datas[b0:b1], labs[b0:b1])
+        sF, sB, sZ = sub.debugBuffer(100), sub.debugBuffer(101), sub.debugBuffer(102)
+        rbs = _packed_rowbase(Ts[b0:b1])
+        for b in range(b0, b1):
+            tt = np.arange(Ts[b])
+            # the recurrence's input W h + b comes out of a time-batched GEMM whose block shape follows the number of
+            # frames: where that already differs in the last bit between the two minibatches, "equal" is not defined
+            if np.array_equal(Z[rb[tt] + b], sZ[rbs[tt] + b - b0]):
+                np.testing.assert_array_equal(hF[rb[tt] + b], sF[rbs[tt] + b - b0])
+                np.testing.assert_array_equal(hB[rb[tt] + b], sB[rbs[tt] + b - b0])
+                n_equal += 1
+            else:
+                np.testing.assert_allclose(hF[rb[tt] + b], sF[rbs[tt] + b - b0], rtol=1e-4, atol=1e-5)
+                np.testing.assert_allclose(hB[rb[tt] + b], sB[rbs[tt] + b - b0], rtol=1e-4, atol=1e-5)
+            n_seen += 1
+        del sub
+    _note("tiled recurrence H=%d B=%d: %d of %d utterances with bit-identical inputs, their hActsFor / hActsBack rows bit-identical to a minibatch of 32"
+         % (H, B, n_equal, n_seen))
+    assert n_equal > 0
+

@@ -13,6 +13,8 @@ if "saturating_batch" in rc:
 if "hbm_resident" in d:
     print("hbm_resident %.0f" % d["hbm_resident"]["value"])
 rr = d.get("roofline_recurrent", {})
+if "minibatch_128" in d:
+    print("minibatch_128", round(d["minibatch_128"]["value"]), "frames/s", round(d["minibatch_128"]["ms_per_step"], 1), "ms")
 if "by_minibatch" in rr:
     print("rec by minibatch", {k: (round(v["us_per_time_step"], 2), round(v["frac_of_f32_mfma_peak"], 3)) for k, v in rr["by_minibatch"].items()})
 for k in ("cfg1_minibatch1", "cfg2_minibatch1"):
