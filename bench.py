@@ -212,6 +212,9 @@ def main():
     ap.add_argument("--no-side", action="store_true",
                     help="skip the PCIe-inclusive and ragged side measurements (profiling runs)")
     ap.add_argument("--batch", type=int, default=CFG["B"], help="utterances per GPU")
+    ap.add_argument("--n1-ms", type=float, default=None,
+                    help="N > 1: the single-GPU step time (ms, HBM-resident features) to compare with; default: measured "
+                         "in this run, every rank stepping alone on its own GPU before the data-parallel steps")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -307,6 +310,10 @@ def main():
             ev_free[k % 2].record(main_stream)
         dp.allreduce_gradients_overlapped(cost_dev, skip_dev)
         net.checkAsync()
+        if dp.time_comm:
+            cs = dp.comm_stats()
+            if cs:
+                comm_acc.append(cs)
         return cost_dev.cpu().numpy(), skip_dev.cpu().numpy().astype(bool)
 
     # roofline leg: asynchronous phase timers (sctc_brnn_set_profiling(h, 2)) -- one hipEvent per
@@ -340,13 +347,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    comm_acc = []
+    n1_ms = args.n1_ms
+    if dp is not None and n1_ms is None:
+        # what ONE GPU does alone with the same per-GPU minibatch (no exchange, HBM-resident features): every rank steps
+        # on its own device at the same time, rank 0's figure is the N = 1 leg of scaling_efficiency_vs_n1
+        net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(max(3, args.steps // 2)):
+            net.costAndGradBatch(None, labels, feats_dev=feats, T_b=Ts)
+        torch.cuda.synchronize()
+        n1_ms = (time.perf_counter() - t0) / max(3, args.steps // 2) * 1e3
+        fence()
     if args.warmup:
         run_steps(args.warmup, resident=False)
     fence()
+    if dp is not None:
+        dp.time_comm = True
     t0 = time.perf_counter()
     cost, skip, step_ev = run_steps(args.steps, resident=False, collect=True)
     fence()
     elapsed = time.perf_counter() - t0
+    if dp is not None:
+        dp.time_comm = False
     # side field: the same K steps with the features already resident in HBM
     run_steps(1, resident=True)
     fence()
@@ -495,6 +519,22 @@ def main():
                     break
             if out["roofline"].get("traffic"):
                 out["roofline"]["traffic_ratio"] = out["roofline"]["traffic"] / (gemm_operand_bytes(cfg) / n_gemm_launches)
+        if dp is not None:
+            # where an N > 1 step's time goes besides compute: the overlapped exchange of the weight gradients
+            # (dist_sgd.comm_stats; rank 0's view, mean over the timed steps) and the same per-GPU work on one GPU alone
+            if comm_acc:
+                out["comm"] = {k: (comm_acc[0][k] if k in ("bytes", "buckets") else float(np.mean([c[k] for c in comm_acc])))
+                               for k in comm_acc[0]}
+                out["comm"]["note"] = ("per step, rank 0, mean of %d timed steps: allreduce_ms = first layer's gradient final -> "
+                                       "last collective finished (side stream; includes waiting for later layers), exposed_ms = "
+                                       "how far that lies behind the end of the backward pass (not hidden), busbw = bytes / "
+                                       "allreduce_ms x 2 (N - 1) / N" % len(comm_acc))
+            res_ms = elapsed_res / args.steps * 1e3
+            out["scaling_efficiency_vs_n1"] = {"value": n1_ms / res_ms if res_ms > 0 else None, "n1_ms": n1_ms,
+                                               "n_ms": res_ms,
+                                               "n1_source": "--n1-ms" if args.n1_ms is not None else "measured in this run (rank 0 alone on its GPU, no exchange)",
+                                               "note": "weak scaling, HBM-resident features on both sides: per-GPU work is fixed, so the efficiency "
+                                                       "is the single-GPU step time over the N-GPU step time"}
         if dp is None and not args.no_side:
             side_measurements(out, net, feats, labels, Ts, rs, torch, B, T, D)
             recurrent_by_minibatch(out, torch, cfg)

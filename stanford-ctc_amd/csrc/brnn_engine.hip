@@ -1067,6 +1067,8 @@ int sctc_brnn_allreduce_grads(sctc_brnn_t h, void* rccl_comm, void* compute_stre
     SCTC_CHECK_ARG(h->grads, "brnn_allreduce_grads: the model has no gradient buffer (train = 0)");
     SCTC_CHECK_ARG(side_stream && side_stream != compute_stream, "brnn_allreduce_grads: needs a side stream of its own");
     SCTC_CHECK_ARG(side_count >= 0 && (side_count == 0 || side_dev), "brnn_allreduce_grads: bad side message");
+    Rccl::AllReduce rccl_all_reduce = nullptr;      // the function pointers are read under the lock that guards their loading
+    Rccl::ErrStr rccl_err_str = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_rccl_mu);
         if (!g_rccl.tried) {
@@ -1078,15 +1080,17 @@ int sctc_brnn_allreduce_grads(sctc_brnn_t h, void* rccl_comm, void* compute_stre
                 g_rccl.err_str = (Rccl::ErrStr)dlsym(g_rccl.lib, "ncclGetErrorString");
             }
         }
+        rccl_all_reduce = g_rccl.all_reduce;
+        rccl_err_str = g_rccl.err_str;
     }
-    if (!g_rccl.all_reduce)
+    if (!rccl_all_reduce)
         return set_error(SCTC_ERR_STATE, "brnn_allreduce_grads: librccl.so (ncclAllReduce) could not be loaded");
     hipStream_t cs = (hipStream_t)compute_stream, ss = (hipStream_t)side_stream;
     constexpr int NCCL_SUM = 0, NCCL_FLOAT = 7, NCCL_DOUBLE = 8;      // rccl.h: ncclSum, ncclFloat32, ncclFloat64
     auto reduce = [&](void* p, size_t n, int dt) -> int {
-        const int rc = g_rccl.all_reduce(p, p, n, dt, NCCL_SUM, rccl_comm, ss);
+        const int rc = rccl_all_reduce(p, p, n, dt, NCCL_SUM, rccl_comm, ss);
         if (rc != 0)
-            return set_error(SCTC_ERR_HIP, "ncclAllReduce failed: %s", g_rccl.err_str ? g_rccl.err_str(rc) : "?");
+            return set_error(SCTC_ERR_HIP, "ncclAllReduce failed: %s", rccl_err_str ? rccl_err_str(rc) : "?");
         return SCTC_OK;
     };
     // an event of our own orders "everything queued on the compute stream so far" in front of the side stream
@@ -1112,7 +1116,10 @@ int sctc_brnn_allreduce_grads(sctc_brnn_t h, void* rccl_comm, void* compute_stre
         rc = reduce(h->grads + h->tinfo[w].offset, (size_t)(slice_end(w + 1) - h->tinfo[w].offset), NCCL_FLOAT);   // W and b
         if (rc == SCTC_OK && i == h->TL) {
             for (int k : {wf_index(h), wb_index(h)}) {
-                if (backward_queued) (void)hipStreamWaitEvent(ss, h->grad_ev[k], 0);
+                if (backward_queued) {      // the recurrent pair's sum must not start before BPTT has written it
+                    const hipError_t e = hipStreamWaitEvent(ss, h->grad_ev[k], 0);
+                    if (e != hipSuccess) { rc = set_error(SCTC_ERR_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(e)); break; }
+                }
                 rc = reduce(h->grads + h->tinfo[k].offset, (size_t)(slice_end(k) - h->tinfo[k].offset), NCCL_FLOAT);
                 if (rc != SCTC_OK) break;
             }

@@ -1,6 +1,7 @@
 // C ABI: library housekeeping + the CTC entry points of include/sctc.h.
 #include <math.h>
 
+#include <atomic>
 #include <vector>
 
 #include "common.h"
@@ -182,9 +183,11 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
     if (pin) {
         memcpy(pin, utts.data(), utt_bytes);
         memcpy(pin + utt_span, labels.data(), lab_bytes);
+        PinnedUploadGuard guard(stream, true);
         SCTC_HIP_TRY(hipMemcpyAsync(d_utts, pin, utt_bytes, hipMemcpyHostToDevice, stream));
         SCTC_HIP_TRY(hipMemcpyAsync(d_labels, pin + utt_span, lab_bytes, hipMemcpyHostToDevice, stream));
         SCTC_HIP_TRY(st.pinned.uploaded(stream));
+        guard.done();
     } else {
         SCTC_HIP_TRY(hipMemcpyAsync(d_utts, utts.data(), utt_bytes, hipMemcpyHostToDevice, stream));
         SCTC_HIP_TRY(hipMemcpyAsync(d_labels, labels.data(), lab_bytes, hipMemcpyHostToDevice, stream));
@@ -206,8 +209,14 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
         fa.cost = cost;
         fa.skip = skip;
         {
+            // timing decomposition of the fused kernel (tools/ctc_diag_timing.py): parts of the schedule are switched
+            // off and the results are WRONG -- never silently
             const char* dz = getenv("SCTC_CTC_DIAG");
             fa.diag = dz ? atoi(dz) : 0;
+            static std::atomic<bool> warned{false};
+            if (fa.diag != 0 && !warned.exchange(true))
+                fprintf(stderr, "sctc: SCTC_CTC_DIAG=%d is set: the fused CTC kernel skips parts of its schedule, costs and "
+                                "gradients are WRONG (diagnostic timing runs only; unset it)\n", fa.diag);
         }
         SCTC_TRY(launch_ctc_fused<R>(fa, plan.B, plan.K, plan.store_bytes, stream));
         if (!staged_pinned) SCTC_HIP_TRY(hipStreamSynchronize(stream));   // pageable staging must outlive the copies

@@ -46,6 +46,7 @@ struct PinnedStage {
     void* pin = nullptr;
     size_t cap = 0;
     hipEvent_t ev = nullptr;
+    int ev_dev = -1;            // device the event belongs to: an event cannot be recorded on another device's stream
     bool pending = false;
     PinnedStage() = default;
     PinnedStage(const PinnedStage&) = delete;
@@ -55,13 +56,23 @@ struct PinnedStage {
         if (ev) { if (pending) (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
         if (pin) (void)hipHostFree(pin);
     }
+    // the staging buffer, free to be overwritten (waits for the previous upload); nullptr: stage from pageable memory
     void* acquire(size_t bytes)
     {
         if (pending) { (void)hipEventSynchronize(ev); pending = false; }
-        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (ev && ev_dev != dev) {      // a per-thread stage used with another GPU's stream: new event there
+            (void)hipEventDestroy(ev);
             ev = nullptr;
-            return nullptr;
+        }
+        if (!ev) {
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                ev = nullptr;
+                return nullptr;
+            }
+            ev_dev = dev;
         }
         if (cap < bytes) {
             if (pin) (void)hipHostFree(pin);
@@ -77,12 +88,28 @@ struct PinnedStage {
         }
         return pin;
     }
+    // after the asynchronous copies out of the buffer have been queued on `s`.  If the event cannot be recorded (a
+    // stream of a device other than the current one), the copies are waited for instead: the buffer is never handed
+    // out again while a copy may still read it.
     hipError_t uploaded(hipStream_t s)
     {
-        const hipError_t e = hipEventRecord(ev, s);
+        hipError_t e = hipEventRecord(ev, s);
         pending = e == hipSuccess;
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipStreamSynchronize(s);
+        }
         return e;
     }
+};
+// Between PinnedStage::acquire and ::uploaded an error return must not leave a queued copy reading a buffer that the
+// next call overwrites: the guard waits for the stream unless uploaded() was reached.
+struct PinnedUploadGuard {
+    hipStream_t s;
+    bool armed;
+    PinnedUploadGuard(hipStream_t stream, bool on) : s(stream), armed(on) {}
+    ~PinnedUploadGuard() { if (armed) (void)hipStreamSynchronize(s); }
+    void done() { armed = false; }
 };
 
 // bump allocator over a caller-provided workspace

@@ -47,10 +47,15 @@ struct RecArgs {
                             // 45: 33..48 utterances as ONE launch of the one-workgroup-per-CU kernel (default: 32 + rest);
                             // 43: the sentinel / VALU kernel for up to 8 utterances (default: up to 3); 44: the single-chain
                             //     flag kernel from 1 utterance (default: from 4)
+                            // 46: exchange tiles row-major throughout (rounds 1-5a; bit-identical A/B of the lane-order layout);
+                            // 47: more than 32 utterances on the one-slab-per-CU kernel of rounds 1-5 (default since round 6 where the
+                            //     layer size has it: units x utterances, brnn_recurrent_t_kernel)
     unsigned* debug;        // nullable: s_memtime stamps [2 wgs][16 steps][8] for steps 64..79
     int32_t b_off;          // rank of this launch's first utterance in the packed minibatch (minibatches of
                             // more than 128 utterances run as several launches; T_b already points at it)
     const int32_t* T_host;  // nullable: host copy of the full (sorted) T_b, used to shorten later launches
+    int32_t linear_map;     // two-chain kernel: linear block -> (chain, producer) map, chain = direction (the single-chain launch of
+                            // 4..16 utterances; set by the launcher -- `variant` keeps its A/B meaning, e.g. 46, there too)
     int32_t prec16;         // != 0: "fp16 activations" -- the 6..16-utterance kernel exchanges the state
                             // and holds the weights in 16 bit (float16 forward, bfloat16 BPTT), fp32 accumulate
 };

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
     // workgroups that land on one CU (k and k+32 of an XCD) still belong to different chains.
     // Placement only affects speed: any block -> XCD assignment gives the same results.
     int chain, wg;
-    if (p.variant != 2) {
+    if (p.variant != 2 && !p.linear_map) {
         const int x = blockIdx.x & 7, k = blockIdx.x >> 3, P = nwg >> 1;   // P blocks per XCD
         const int gx = x >> 2, xl = x & 3;
         const int n0_even = (P + 1) >> 1, n0_odd = P >> 1;                  // chain-0 share per XCD
@@ -2526,7 +2526,8 @@ static int launch_recurrent_one(const RecArgs& a, const LaunchCtx& cx)
         }
         if (qk) {
             RecArgs b = a;
-            b.variant = 2;      // linear block -> (chain, producer) map: chain = direction, tile 0 only
+            b.linear_map = 1;   // linear block -> (chain, producer) map: chain = direction, tile 0 only (variant keeps its A/B meaning)
+            if (b.variant == 44) b.variant = 0;
             const size_t smem = sizeof(float4) * ((size_t)4 * (ncq - nreg) * 64 + 3 * 64);
             SCTC_TRY(launch_persistent(qk, 2 * nwg, smem, 2, 0, b, cx, &done));
             if (done) return SCTC_OK;

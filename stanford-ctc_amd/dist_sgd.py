@@ -67,7 +67,7 @@ def allreduce_flat(flat, side, bucket_elems=DEFAULT_BUCKET_ELEMS, group=None):
     return flat, side
 
 
-def allreduce_overlapped(net, side, group=None, side_stream=None, backward_queued=True):
+def allreduce_overlapped(net, side, group=None, side_stream=None, backward_queued=True, timing=None):
     """Sum-all-reduce net's flat gradient buffer bucket by bucket WHILE the backward pass queued
     on the current stream is still running: a side stream waits for the event the
     engine records when a layer's gradient is final (output layer first) and starts that layer's
@@ -76,7 +76,11 @@ def allreduce_overlapped(net, side, group=None, side_stream=None, backward_queue
     reduced last.  On return the CURRENT stream has been made to wait for all of it.
     `backward_queued=False`: this rank queued no backward pass this step (empty shard; its gradient
     buffer was zeroed on the current stream instead) -- the engine's events are then stale or were
-    never recorded, so the side stream is ordered behind the current stream as a whole."""
+    never recorded, so the side stream is ordered behind the current stream as a whole.
+    `timing`: a dict that receives three timing events of this exchange -- "first_start" (side stream, the first
+    bucket's gradient is final: its all-reduce starts), "last_end" (side stream, every collective has finished),
+    "backward_end" (current stream, behind the backward pass as queued so far) -- plus "bytes" and "buckets";
+    comm_stats(timing) turns them into milliseconds once the streams have been synchronised."""
     import torch
     import torch.distributed as dist
     import _sctc
@@ -87,19 +91,51 @@ def allreduce_overlapped(net, side, group=None, side_stream=None, backward_queue
     cur = torch.cuda.current_stream()
     st = side_stream or torch.cuda.Stream()
     works = []
+    if timing is not None:
+        timing.clear()
+        timing["backward_end"] = torch.cuda.Event(enable_timing=True)
+        timing["backward_end"].record(cur)
+        timing["bytes"] = 0
+        timing["buckets"] = 0
     with torch.cuda.stream(st):
         if not backward_queued:
             st.wait_stream(cur)                    # the zero fill, not a stale event, orders the buckets
         for ev, start, end in net.gradBuckets():
             if backward_queued:
                 _sctc.check(L.sctc_stream_wait_event(st.cuda_stream, ev), "stream_wait_event")
+            if timing is not None:
+                if "first_start" not in timing:
+                    timing["first_start"] = torch.cuda.Event(enable_timing=True)
+                    timing["first_start"].record(st)
+                timing["bytes"] += (end - start) * flat.element_size()
+                timing["buckets"] += 1
             works.append(dist.all_reduce(flat[start:end], op=dist.ReduceOp.SUM, group=group,
                                          async_op=True))
         st.wait_stream(cur)                        # `side` is produced on the compute stream
         works.append(dist.all_reduce(side, op=dist.ReduceOp.SUM, group=group, async_op=True))
         for w in works:
             w.wait()                               # the side stream waits for the collectives
+        if timing is not None:
+            timing["bytes"] += side.numel() * side.element_size()
+            timing["buckets"] += 1
+            timing["last_end"] = torch.cuda.Event(enable_timing=True)
+            timing["last_end"].record(st)
     cur.wait_stream(st)
+
+
+def comm_stats(timing, world):
+    """milliseconds and bandwidths of one overlapped exchange (allreduce_overlapped(..., timing=...)), after its streams
+    have been synchronised: allreduce_ms = first bucket's start -> last collective's end (the span the exchange occupies
+    on the side stream, waits for later layers' gradients included); exposed_ms = how far that end lies BEHIND the end
+    of the backward pass on the compute stream (the part of the exchange that is not hidden; 0 when it finishes first);
+    algbw = bytes / allreduce_ms; busbw = algbw x 2 (N - 1) / N (the ring / tree-independent figure of nccl-tests)."""
+    if not timing or "last_end" not in timing or "first_start" not in timing:
+        return None
+    span = timing["first_start"].elapsed_time(timing["last_end"])
+    exposed = max(0.0, timing["backward_end"].elapsed_time(timing["last_end"]))
+    algbw = timing["bytes"] / (span * 1e-3) / 1e9 if span > 0 else 0.0
+    return {"bytes": int(timing["bytes"]), "buckets": int(timing["buckets"]), "allreduce_ms": span,
+            "exposed_ms": exposed, "algbw_GBps": algbw, "busbw_GBps": algbw * 2.0 * (world - 1) / max(1, world)}
 
 
 class DataParallel(object):
@@ -110,6 +146,8 @@ class DataParallel(object):
         self.bucket_elems = bucket_elems
         self.group = group
         self._side_stream = None
+        self.time_comm = False      # record timing events around the overlapped exchange (bench.py: the `comm` field)
+        self._timing = {}
         self.n_valid = 0
         self.cost_sum = 0.0
         self.regcost = 0.0
@@ -165,5 +203,12 @@ class DataParallel(object):
             side[2] = regcost_local
             side[3] = 1.0
         allreduce_overlapped(self.net, side, self.group, self._side_stream,
-                             backward_queued=cost_dev is not None)
+                             backward_queued=cost_dev is not None, timing=self._timing if self.time_comm else None)
         return self._finish(side)
+
+    def comm_stats(self):
+        """timings of the last overlapped exchange (see comm_stats above); needs time_comm = True before the step and
+        a synchronised device (allreduce_gradients_overlapped ends in one); None if nothing was exchanged"""
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        return comm_stats(self._timing, world)

@@ -186,6 +186,13 @@ def test_bench_gpus2_without_a_launcher():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["frames_per_step"] == 2 * 6 * 1000 and out["cost_check"]["rel_err"] < 1e-4
     assert "without a launcher" in res.stderr
+    # the N > 1 line explains itself (round 6): what the gradient exchange moved, how long it occupied the side stream,
+    # how much of it was NOT hidden behind the backward pass, and the same per-GPU work on one GPU alone
+    comm = out["comm"]
+    assert comm["bytes"] > 4 * 20e6 and comm["buckets"] >= 7 and comm["allreduce_ms"] > 0
+    assert 0 <= comm["exposed_ms"] <= comm["allreduce_ms"] + 1e-3 and comm["busbw_GBps"] > 0
+    eff = out["scaling_efficiency_vs_n1"]
+    assert eff["n1_ms"] > 0 and eff["n_ms"] > 0 and 0 < eff["value"] < 1.5
     # a failing rank's exit status comes back through the self-launch
     bad = subprocess.run(cmd[:2] + ["--gpus", "2", "--batch", "0", "--steps", "1", "--warmup", "0", "--no-side",
                                     "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
@@ -308,6 +315,10 @@ def test_bench_single_rank_rccl():
     assert d["config"]["parallelism"].startswith("dp1") and s["config"]["parallelism"] == "single-gpu"
     assert d["cost_mean"] == s["cost_mean"]                 # same kernels, same order: bit-identical costs
     assert d["cost_check"]["rel_err"] < 1e-4
+    comm = d["comm"]                                        # one rank: real RCCL calls, nothing to move over a link
+    assert comm["bytes"] > 4 * 20e6 and comm["buckets"] >= 7 and comm["allreduce_ms"] > 0 and comm["busbw_GBps"] == 0
+    assert 0 <= comm["exposed_ms"] <= comm["allreduce_ms"] + 1e-3
+    assert 0.7 < d["scaling_efficiency_vs_n1"]["value"] < 1.3 and "comm" not in s
     # bookkeeping only (a one-rank all-reduce moves no data): measured +1 %; the bound is loose because
     # three timed steps on a box shared with the harness are noisy
     assert d["ms_per_step"] < 1.15 * s["ms_per_step"] + 1.0, (d["ms_per_step"], s["ms_per_step"])
