@@ -745,6 +745,40 @@ def ctc_saturation(out, torch, A, T, U):
                 "r05_ctc_paths_kernel_stats.csv), `ms_wall` the Python entry ctc_loss_batch with its 4096 label arrays "
                 "(rounds 1-4 reported that one: 11.4 ms with the three-kernel path).  The float64 recursion is "
                 "latency/issue-bound, not HBM-bound (DESIGN.md 4.3)" % (T, U)}
+    # Which bound it IS on cannot be sampled from inside this process: the SQ counters of the same kernel at the same batch
+    # come from the committed rocprofv3 --pmc passes (tools/profile_ctc_bound.sh -> profiles/r*_ctc_bound_sat.json),
+    # read back only if they were measured on these CTC sources
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ctc_bound_sat.json")))
+    if files:
+        pm = json.load(open(files[-1]))
+        h = hashlib.sha256()
+        for f in ("ctc_fused.hip", "ctc_kernels.h", "xlane.h", "common.h"):
+            h.update(open(os.path.join(ROOT, "stanford-ctc_amd", "csrc", f), "rb").read())
+        sat = out["roofline_ctc"]["saturating_batch"]
+        if pm.get("source_hash_ctc") != h.hexdigest()[:16]:
+            sat["bound_note"] = "%s was measured on other CTC sources: not used; re-run tools/profile_ctc_bound.sh" % os.path.basename(files[-1])
+        else:
+            k = [v for n, v in pm["kernels"].items() if "ctc_fused_kernel" in n]
+            if k:
+                k = k[0]
+                util = k.get("simd_valu_util")
+                sat["valu_busy"] = util
+                sat["bound"] = ("fp64-issue" if util is not None and util >= 0.8 else
+                                "latency" if util is not None and util < 0.6 else "issue + latency")
+                sat["counters"] = {"simd_valu_util": util, "wave_valu_busy": k.get("valu_busy"), "wave_issue_busy": k.get("issue_busy"),
+                                   "wave_parked": k.get("parked"), "wave_issue_stalled": k.get("issue_stalled"),
+                                   "float64_share_of_valu_instructions": k.get("float64_share_of_valu_instructions"),
+                                   "valu_instructions_per_wave_and_frame": k["per_wave"]["valu"] / T if "per_wave" in k else None,
+                                   "shader_clock_GHz_while_profiled": k.get("shader_clock_GHz_while_profiled"),
+                                   "source": os.path.basename(files[-1])}
+                sat["bound_note"] = ("SQ counters of ctc_fused_kernel at this batch (rocprofv3 --pmc, %s): the device's SIMDs execute a VALU "
+                                     "instruction in valu_busy of their cycles with two recursion waves per SIMD (194 registers); a wave has one "
+                                     "executing in wave_valu_busy of its resident time, waits at s_waitcnt / barriers in wave_parked and on "
+                                     "dependencies in wave_issue_stalled: neither the float64 pipe's issue slots (>= 0.8) nor latency alone (< 0.6) -- "
+                                     "HBM is not the bound at any batch" % os.path.basename(files[-1]))
+                out["roofline_ctc"]["bound"] = "issue + latency (float64 recursion; see saturating_batch.bound / valu_busy); HBM fraction reported for the record"
 
 
 def f32_split_bf16x3(out, torch, cfg, labels, feats, net32):
