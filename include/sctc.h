@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SCTC_ABI_VERSION 5
+#define SCTC_ABI_VERSION 6
 
 #define SCTC_OK 0
 #define SCTC_ERR_ARG (-1)       /* bad argument (the reference raises ValueError/AssertionError) */
@@ -257,6 +257,17 @@ int sctc_brnn_recurrent_path(sctc_brnn_t h, int32_t* forward_path, int32_t* bptt
 /* NNet(train=False).costAndGrad(data) (brnnet.py:171-173): probs_dev float [sum T][output_dim],
  * caller order, each utterance the reference's (outputDim,T) F-order probs */
 int sctc_brnn_forward(sctc_brnn_t h, const sctc_minibatch* mb, float* probs_dev, void* stream);
+
+/* The CTC scratch of a step lives in the model's workspace, which reserves 2048 lattice states (2U+1) per frame and
+ * utterance slot.  The reference bounds no label row (ctc_fast.pyx:22-32 allocates (2U+1) x T per call): a minibatch
+ * with a longer row may need more.  sctc_brnn_ctc_workspace_bytes says how much THIS minibatch needs (*needed) and
+ * how much the handle currently offers (*reserved: its own share, or what was last set); a caller that finds
+ * needed > reserved allocates a device buffer of at least `needed` bytes and hands it over with
+ * sctc_brnn_set_ctc_workspace -- it replaces the built-in share for all later steps and stays OWNED BY THE CALLER, who
+ * keeps it alive until it sets another one, resets (dev = NULL) or destroys the handle.  Without this a step whose
+ * CTC scratch does not fit returns SCTC_ERR_WORKSPACE.  (nnets/brnnet.py does this by itself: round 6.) */
+int sctc_brnn_ctc_workspace_bytes(sctc_brnn_t h, const sctc_minibatch* mb, size_t* needed, size_t* reserved);
+int sctc_brnn_set_ctc_workspace(sctc_brnn_t h, void* workspace_dev, size_t workspace_bytes);
 
 /* rocprof-free timing hooks: milliseconds spent in the phases of the last call, measured with hipEvents
  * on the step's stream.  sctc_brnn_set_profiling(h, 1): exact phase timers that synchronise the

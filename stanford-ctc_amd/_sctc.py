@@ -80,6 +80,9 @@ PROTOTYPES = {
     "sctc_brnn_grad_event": (vp, [vp, ctypes.c_int32]),
     "sctc_stream_wait_event": (ctypes.c_int, [vp, vp]),
     "sctc_brnn_forward": (ctypes.c_int, [vp, ctypes.POINTER(Minibatch), vp, vp]),
+    "sctc_brnn_ctc_workspace_bytes": (ctypes.c_int, [vp, ctypes.POINTER(Minibatch), ctypes.POINTER(ctypes.c_size_t),
+                                                     ctypes.POINTER(ctypes.c_size_t)]),
+    "sctc_brnn_set_ctc_workspace": (ctypes.c_int, [vp, vp, ctypes.c_size_t]),
     "sctc_brnn_set_profiling": (ctypes.c_int, [vp, ctypes.c_int32]),
     "sctc_brnn_debug_read": (ctypes.c_int, [vp, vp, ctypes.c_int32]),
     "sctc_brnn_debug_buffer": (ctypes.c_int, [vp, ctypes.c_int32, ctypes.POINTER(vp), c_i64p, c_i64p, c_i64p]),
@@ -190,7 +193,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if L.sctc_abi_version() != 5:
+        if L.sctc_abi_version() != 6:
             raise ImportError("libsctc_hip.so ABI version mismatch")
         _lib = L
         # shared-device mode is not guessed here: the library finds out by itself how many processes use

@@ -76,6 +76,8 @@ struct sctc_brnn {
     int32_t *d_rowbase, *d_nact, *d_Ts, *d_src_row, *d_idx_lo, *d_idx_hi, *d_xbase;
     void* ctc_ws;
     size_t ctc_ws_bytes;
+    void* ctc_ws_ext = nullptr;     // caller-owned replacement (sctc_brnn_set_ctc_workspace): label rows beyond the reserved share
+    size_t ctc_ws_ext_bytes = 0;
     float* splitk_ws;
     int64_t splitk_floats;
     float* xbuf;
@@ -656,8 +658,8 @@ static int run_ctc(sctc_brnn* h, const sctc_minibatch* mb, hipStream_t s)
     bt.label_off = label_off.data();
     bt.rowbase_dev = h->d_rowbase;
     if (!h->ctc_stage) h->ctc_stage = ctc_new_stage();
-    return ctc_run_batch(&bt, h->probs, h->dlogits, h->d_cost, h->d_skip, h->ctc_ws,
-                         h->ctc_ws_bytes, s, h->ctc_stage);
+    return ctc_run_batch(&bt, h->probs, h->dlogits, h->d_cost, h->d_skip, h->ctc_ws_ext ? h->ctc_ws_ext : h->ctc_ws,
+                         h->ctc_ws_ext ? h->ctc_ws_ext_bytes : h->ctc_ws_bytes, s, h->ctc_stage);
 }
 
 __global__ void unpermute_results_kernel(const double* cost, const int32_t* skip,
@@ -1271,6 +1273,29 @@ int sctc_brnn_debug_buffer(sctc_brnn_t h, int32_t which, void** dev_ptr, int64_t
     *rows = h->N;
     *cols = c;
     *ld = l;
+    return SCTC_OK;
+}
+
+int sctc_brnn_ctc_workspace_bytes(sctc_brnn_t h, const sctc_minibatch* mb, size_t* needed, size_t* reserved)
+{
+    SCTC_CHECK_ARG(h && mb && needed, "brnn_ctc_workspace_bytes: null argument");
+    SCTC_CHECK_ARG(h->cfg.train, "brnn_ctc_workspace_bytes: the model was created with train = 0 (no CTC)");
+    SCTC_CHECK_ARG(mb->B >= 1 && mb->B <= h->cfg.max_utts && mb->T_b && mb->U_b, "brnn_ctc_workspace_bytes: bad minibatch");
+    CtcPlan plan;
+    SCTC_TRY(ctc_make_plan(mb->B, h->A, 0, SCTC_F32, mb->T_b, mb->U_b, &plan));
+    *needed = plan.bytes;
+    if (reserved) *reserved = h->ctc_ws_ext ? h->ctc_ws_ext_bytes : h->ctc_ws_bytes;
+    return SCTC_OK;
+}
+
+int sctc_brnn_set_ctc_workspace(sctc_brnn_t h, void* workspace_dev, size_t workspace_bytes)
+{
+    SCTC_CHECK_ARG(h, "null handle");
+    SCTC_CHECK_ARG(h->cfg.train, "brnn_set_ctc_workspace: the model was created with train = 0 (no CTC)");
+    SCTC_CHECK_ARG((workspace_dev == nullptr) == (workspace_bytes == 0), "brnn_set_ctc_workspace: a buffer and its size, or NULL and 0");
+    SCTC_CHECK_ARG(((uintptr_t)workspace_dev & 255) == 0, "brnn_set_ctc_workspace: the buffer must be 256-byte aligned");
+    h->ctc_ws_ext = workspace_dev;
+    h->ctc_ws_ext_bytes = workspace_bytes;
     return SCTC_OK;
 }
 

@@ -193,6 +193,25 @@ class NNet:
             o += r.shape[0]
         return dev
 
+    def _grow_ctc_workspace(self, mb, h=None):
+        """The reference allocates its lattices per call, (2U+1) x T, with no bound (ctc_fast.pyx:22-32); the model's
+        workspace reserves 2048 lattice states per frame.  A minibatch with a longer label row gets a CTC scratch of its
+        own size here (kept, and only ever grown), instead of SCTC_ERR_WORKSPACE -- rounds 1-5 made the trainer skip
+        such utterances."""
+        torch = _sctc.require_gpu()
+        need, have = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        _sctc.check(_sctc.lib().sctc_brnn_ctc_workspace_bytes(h or self._h, ctypes.byref(mb), ctypes.byref(need),
+                                                              ctypes.byref(have)), "ctc workspace")
+        if need.value > have.value:
+            torch.cuda.synchronize()             # a step that still uses the previous scratch may be in flight
+            ws = torch.empty(need.value + need.value // 8, dtype=torch.uint8, device="cuda")
+            _sctc.check(_sctc.lib().sctc_brnn_set_ctc_workspace(h or self._h, ws.data_ptr(), ws.numel()), "ctc workspace")
+            if h is None or h == self._h:
+                self._ctc_ws = ws
+            else:
+                self._lane_ctc_ws = getattr(self, "_lane_ctc_ws", {})
+                self._lane_ctc_ws[int(getattr(h, "value", h) or 0)] = ws
+
     def _minibatch(self, feats_dev, T_b, labels_list):
         T_arr = np.ascontiguousarray(T_b, dtype=np.int32)
         keep = [T_arr]
@@ -203,6 +222,8 @@ class NNet:
             keep += [U_arr, lab]
             mb = _sctc.Minibatch(len(T_arr), _sctc.i32(T_arr), feats_dev.data_ptr(),
                                  _sctc.i32(lab), _sctc.i32(U_arr))
+            if self.train and U_arr.size and int(U_arr.max()) > 1023 and self._h is not None:
+                self._grow_ctc_workspace(mb)     # a label row beyond the 2048 states the workspace reserves per frame
         else:
             mb = _sctc.Minibatch(len(T_arr), _sctc.i32(T_arr), feats_dev.data_ptr(), None, None)
         return mb, keep
@@ -336,6 +357,8 @@ class NNet:
             mb, kp = self._minibatch(feats_dev[off:off + T_b[i]], [T_b[i]], [labels_list[i]])
             keep.append((mb, kp))
             off += T_b[i]
+            if len(labels_list[i]) > 1023 and ln["h"] is not self._h:
+                self._grow_ctc_workspace(mb, h=ln["h"])   # this lane's engine has a workspace of its own
             flags = (_sctc.FLAG_ACCUMULATE if used[k] else 0) | \
                     (0 if (reg_in_grad and i == 0) else _sctc.FLAG_NO_REG_GRAD)
             if used[k]:

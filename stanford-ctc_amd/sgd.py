@@ -28,10 +28,11 @@ LATTICE_STATES_RESERVED = 2048  # lattice row the engine's workspace reserves pe
 
 
 def lattice_fits(T, U, max_frames):
-    """Round 5: label rows of any length run (ctc_generic.hip beyond 2U+1 = 2048, like the reference, which has no
-    bound: ctc_fast.pyx:22-32).  What is left is the workspace the model was created with: it reserves 2048 lattice
-    states for each of its maxBatch frames per utterance slot, so a longer label row fits while T x round_up(2U+2,
-    64) stays within that share (a 3001-state row fits an utterance of up to two thirds of maxBatch frames)."""
+    """Whether an utterance's CTC scratch fits the share of the workspace the model was created with (2048 lattice states
+    for each of its maxBatch frames).  Round 5 made the trainer skip utterances for which this is False; since round 6
+    nnets.brnnet grows the CTC scratch for such a minibatch by itself (sctc_brnn_ctc_workspace_bytes /
+    sctc_brnn_set_ctc_workspace), like the reference, which allocates its lattices per call with no bound
+    (ctc_fast.pyx:22-32) -- the trainer no longer asks.  Kept as a statement of what needs no extra allocation."""
     L = 2 * U + 1
     if L <= LATTICE_STATES_RESERVED:
         return True
@@ -164,11 +165,10 @@ class SGD:
                 logging.info("SKIPPING utt frames less than label length (Utterance length %d, "
                              "Num Labels %d)." % (mb_data.shape[1], mb_labels.shape[0]))
                 continue
-            # conditions the engine rejects (the reference would index out of bounds; a label row beyond 2048
-            # states that does not fit the workspace share of its utterance slot): one bad utterance must not
-            # end the run
-            if mb_labels.shape[0] < 1 or not lattice_fits(mb_data.shape[1], mb_labels.shape[0], self.maxBatch) or \
-                    mb_labels.min() < 0 or mb_labels.max() >= self.model.outputDim:
+            # conditions the engine rejects (the reference would index out of bounds): one bad utterance must not end
+            # the run.  (A label row beyond the 2048 lattice states the workspace reserves per frame is NOT one of them
+            # any more: the model grows its CTC scratch, round 6.)
+            if mb_labels.shape[0] < 1 or mb_labels.min() < 0 or mb_labels.max() >= self.model.outputDim:
                 logging.info("SKIPPING utt with unusable labels (Num Labels %d, ids %s..%s)."
                              % (mb_labels.shape[0], mb_labels.min() if mb_labels.size else '-',
                                 mb_labels.max() if mb_labels.size else '-'))

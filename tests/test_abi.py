@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(sctc):
     for n in names:
         assert hasattr(L, n), "libsctc_hip.so does not export %s" % n
     assert sorted(sctc.PROTOTYPES) == names, "ctypes prototypes out of sync with include/sctc.h"
-    assert L.sctc_abi_version() == 5        # v5: sctc_brnn_allreduce_grads (v4: sctc_device_pci_bus_id; v3: shared-device mode, recurrent_path)
+    assert L.sctc_abi_version() == 6        # v6: sctc_brnn_ctc_workspace_bytes / _set_ctc_workspace; v5: sctc_brnn_allreduce_grads (v4: sctc_device_pci_bus_id; v3: shared-device mode, recurrent_path)
 
 
 def test_struct_mirrors_match_the_header(sctc, tmp_path):

@@ -277,35 +277,63 @@ def test_wide_alphabet_through_the_network(mods):
 
 
 def test_long_label_row_through_the_network_and_the_trainer_check(mods):
-    """NNet.costAndGrad on an utterance whose label row has 2201 lattice states (rounds 1-4: SCTC_ERR_ARG, the trainer
-    skipped it): cost and gradients against the float64 oracle; sgd.lattice_fits says what the workspace share of an
-    utterance slot holds"""
+    """NNet.costAndGrad on utterances whose label row has 2201 lattice states (rounds 1-4: SCTC_ERR_ARG, the trainer
+    skipped them): one that fits the workspace's share of 2048 states per frame (T = 1300) and, round 6, one that does
+    NOT (T = 2000 = maxBatch: round 5 returned SCTC_ERR_WORKSPACE and the trainer skipped it) -- the model grows its CTC
+    scratch for that minibatch (sctc_brnn_ctc_workspace_bytes / sctc_brnn_set_ctc_workspace), like the reference, which
+    allocates (2U+1) x T per call (ctc_fast.pyx:22-32).  Cost and gradients against the float64 oracle; a minibatch of a
+    long and a short row; the C entries' argument checks"""
     cf, octc, torch = mods
+    import ctypes
     from nnets import brnnet
     from oracle import brnn as obrnn
     import sgd
-    D, A, H, NL, TL, T, U, maxBatch = 8, 20, 32, 2, 1, 1300, 1100, 2000
-    assert sgd.lattice_fits(T, U, maxBatch) and sgd.lattice_fits(8000, 800, 8000)
+    import _sctc
+    D, A, H, NL, TL, U, maxBatch = 8, 20, 32, 2, 1, 1100, 2000
+    assert sgd.lattice_fits(1300, U, maxBatch) and sgd.lattice_fits(8000, 800, 8000)
     assert not sgd.lattice_fits(2000, 1100, maxBatch) and sgd.lattice_fits(2000, 1023, maxBatch)
     rs = np.random.RandomState(8)
-    data = rs.randn(D, T)
-    labels = rs.randint(1, A, size=U).astype(np.int32)
     np.random.seed(3)
     net = brnnet.NNet(D, A, H, NL, maxBatch, temporalLayer=TL)
     net.initParams()
     np.random.seed(3)
     params = obrnn.init_params(D, A, H, NL, TL)
-    cost, grad, skip = net.costAndGrad(data, labels)
+    for T in (1300, 2000):
+        data = rs.randn(D, T)
+        labels = rs.randint(1, A, size=U).astype(np.int32)
+        cost, grad, skip = net.costAndGrad(data, labels)
+        with np.errstate(all="ignore"):
+            c_ref, g_ref, s_ref, _ = obrnn.cost_and_grad(params, data, labels, TL, max_act=20.0)
+        assert not skip and not s_ref
+        assert abs(cost - c_ref) <= 1e-4 * abs(c_ref), (T, cost, c_ref)
+        for (dw, db), gw in zip(grad[:NL + 1], g_ref["W"]):
+            assert np.linalg.norm(dw.copy_to_host() - gw) <= 2e-4 * np.linalg.norm(gw) + 1e-7
+        assert (getattr(net, "_ctc_ws", None) is not None) == (T == 2000)     # grown only when the share is too small
+    # a minibatch: the long row next to a short one (the generic path's scratch rows take the widest row of the batch,
+    # ADVICE r05), against the two single-utterance results
+    netb = brnnet.NNet(D, A, H, NL, maxBatch, temporalLayer=TL, maxUtts=2)
+    netb.setParams([[w.copy_to_host(), b.copy_to_host()] for w, b in net.stack])
+    datas = [rs.randn(D, 1200), rs.randn(D, 800)]
+    labs = [rs.randint(1, A, size=U).astype(np.int32), rs.randint(1, A, size=30).astype(np.int32)]
+    costs, _, skips = netb.costAndGradBatch(datas, labs)
     with np.errstate(all="ignore"):
-        c_ref, g_ref, s_ref, _ = obrnn.cost_and_grad(params, data, labels, TL, max_act=20.0)
-    assert not skip and not s_ref
-    assert abs(cost - c_ref) <= 1e-4 * abs(c_ref), (cost, c_ref)
-    for (dw, db), gw in zip(grad[:NL + 1], g_ref["W"]):
+        cr, gr, sr, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+    assert not skips.any() and not sr.any()
+    np.testing.assert_allclose(costs, cr, rtol=1e-4)
+    for (dw, db), gw in zip(netb.grad[:NL + 1], gr["W"]):
         assert np.linalg.norm(dw.copy_to_host() - gw) <= 2e-4 * np.linalg.norm(gw) + 1e-7
-    # a row that does not fit the share is a workspace error of the library, not a wrong answer
-    import _sctc
-    with pytest.raises((_sctc.SctcError, ValueError)):
-        net.costAndGrad(rs.randn(D, 2000), rs.randint(1, A, size=1100).astype(np.int32))
+    # the C entries: what a minibatch needs against what the handle offers; argument errors
+    L = _sctc.lib()
+    mb, keep = netb._minibatch(netb._stage(datas), [1200, 800], labs)
+    need, have = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert L.sctc_brnn_ctc_workspace_bytes(netb._h, ctypes.byref(mb), ctypes.byref(need), ctypes.byref(have)) == 0
+    assert 0 < need.value <= have.value
+    assert L.sctc_brnn_set_ctc_workspace(netb._h, ctypes.c_void_p(256), 0) == -1
+    assert L.sctc_brnn_set_ctc_workspace(netb._h, None, 0) == 0          # back to the built-in share
+    assert L.sctc_brnn_ctc_workspace_bytes(netb._h, ctypes.byref(mb), ctypes.byref(need), ctypes.byref(have)) == 0
+    netf = brnnet.NNet(D, A, H, NL, 100, train=False, temporalLayer=TL)
+    netf.setParams([[w.copy_to_host(), b.copy_to_host()] for w, b in net.stack])
+    assert L.sctc_brnn_set_ctc_workspace(netf._h, None, 0) == -1     # a forward-only model has no CTC
 
 
 @pytest.mark.parametrize("which", ["fused", "fused2w", "lattice", "generic"])
