@@ -690,7 +690,7 @@ __device__ __forceinline__ void static_for(F&& f)
     static_for_seq(std::make_integer_sequence<int, N>(), static_cast<F&&>(f));
 }
 
-template <int NCQ, int NREGF, int NT, int NBAT, int R, int PUB>
+template <int NCQ, int NREGF, int NT, int NBAT, int R, int PUB, int PB>
 __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
@@ -701,7 +701,9 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
     static_assert(NC <= 4, "one result per wave");
     static_assert(NBAT % R == 0 && NBAT >= 2 * R && R >= 2, "ring");
     static_assert((NBAT - 1) * XB < NCQ, "no empty batch");
-    static_assert(PUB >= 0 && PUB < NBAT - R, "the flag is published before the next phase's flags are polled");
+    static_assert(PUB >= 0 && PUB + 2 <= PB && PB <= NBAT - R + 1 && PB >= 1,
+                  "the flag is published (behind batch PUB) before the next phase's flags are polled (in front of batch PB - 1) and "
+                  "seen (in front of batch PB), and that before the next phase's first exchange loads (batch NBAT - R + 1)");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Hp = p.Hp, nch = Hp >> 4, nprod = Hp >> 5;
@@ -799,16 +801,28 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
     // (kept in LDS and written out at the end: a store inside the time loop would change the counted waits)
     const int dbg_sel = (p.debug && combo == 0 && tid == 0) ? (ublk == 0 ? 0 : (ublk == nprod - 1 ? 1 : -1)) : -1;
     unsigned* dbg_lds = reinterpret_cast<unsigned*>(red + (size_t)2 * NC * 3 * 64);      // [16][8]
+    // SCTC_T_STAMPS builds only (tools/build_variant.sh recurrent.hip -DSCTC_T_STAMPS; tools/rec_tiled_timeline.py): eight
+    // branches per phase in the production kernel are 0.1-0.2 us of its 8.5
+#if defined(SCTC_T_STAMPS) || defined(SCTC_T_STAMP_CHUNKS)
     auto stamp = [&](int sub, int j, int k) {
         if (dbg_sel >= 0 && j >= 64 && j < 72)
             dbg_lds[((j - 64) * 2 + sub) * 8 + k] = (unsigned)wall_clock64();
     };
-    // a stamp behind every chunk of steps 64..67: [(step - 64) * 2 + sub][32], written out behind the [512][8] region's head
+#else
+    auto stamp = [&](int, int, int) {};
+    (void)dbg_lds;
+#endif
+    // (a stamp behind every chunk, SCTC_T_STAMP_CHUNKS builds only: 29 more branches per phase; [(step - 64) * 2 + sub][32],
+    // written out behind the [512][8] region's head; tools/rec_tiled_timeline.py prints the profile when it finds one)
+#ifdef SCTC_T_STAMP_CHUNKS
     unsigned* dbg_fine = dbg_lds + 16 * 8;
     auto stamp_chunk = [&](int sub, int j, int c) {
         if (dbg_sel >= 0 && j >= 64 && j < 68 && c < 32)
             dbg_fine[((j - 64) * 2 + sub) * 32 + c] = (unsigned)wall_clock64();
     };
+#else
+    auto stamp_chunk = [&](int, int, int) {};
+#endif
 
     float4 x[R][XB][NT];
 
@@ -1064,11 +1078,11 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
                 // batch 0: the previous phase's epilogue in pieces behind groups NC-1 .., then the loads, one per group;
                 // other batches: a load behind every second group
 #define SCTC_T_SLOT(piece) (NC - 1 + (piece) < NG - 1 ? NC - 1 + (piece) : NG - 1)
-                if constexpr (b == NBAT - R) {
+                if constexpr (b == PB - 1) {
                     fl = poll_issue(nfl_off);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (b == NBAT - R + 1) {
+                if constexpr (b == PB) {
                     if (pre_next) {
                         wait_flags(nfl_off, poll_min(fl), (unsigned)jn);
                         xin_of(N, jn, N.xb_cur, xin_n);
@@ -1159,10 +1173,14 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
             if (jc < cur.T) prologue(cur, jc);
         }
     }
+#if defined(SCTC_T_STAMPS) || defined(SCTC_T_STAMP_CHUNKS)
     if (dbg_sel >= 0) {
         for (int i = 0; i < 16 * 8; ++i) p.debug[dbg_sel * 16 * 8 + i] = dbg_lds[i];
+#ifdef SCTC_T_STAMP_CHUNKS
         for (int i = 0; i < 8 * 32; ++i) p.debug[REC_DEBUG_ALL_OFF + dbg_sel * 8 * 32 + i] = dbg_fine[i];
+#endif
     }
+#endif
 }
 
 #ifdef SCTC_REC_EXPERIMENTS    // measured slower / superseded kernels, kept for the A/Bs of profiles/r04_recurrence_q8.md and r05 (build with -DSCTC_REC_EXPERIMENTS)
@@ -2633,21 +2651,25 @@ static int launch_recurrent_one(const RecArgs& a, const LaunchCtx& cx)
         RecKernel tk = nullptr;
         const bool one = ntiles <= 4;       // one utterance tile per sub-chain
         int nldsf = 0;
-        // <chunks per wave, weight fragments in registers, tiles per sub-chain, batches per phase, ring depth, publish batch>;
-        // SCTC_REC_TCFG=1: six batches, ring of three (A/B of the schedule, tools/rec_tiled_sweep.sh: equal within the noise)
+        // <chunks per wave, weight fragments in registers, tiles per sub-chain, batches per phase, ring depth, publish batch,
+        // batch in front of which the next phase's flags are checked>; SCTC_REC_TCFG=1: the other of (eight batches, ring of
+        // four) / (six, three) (A/B of the schedule, tools/rec_tiled_sweep.sh: equal within the noise); 2: ring of two (one batch of lookahead: 128 utterances
+        // 19.5 instead of 17.2 us per step -- the ring's depth is what hides the exchange loads' latency)
         static const int tcfg = getenv("SCTC_REC_TCFG") ? atoi(getenv("SCTC_REC_TCFG")) : 0;
         switch (nwg) {
-            case 32:  tk = one ? brnn_recurrent_t_kernel<8, 0, 1, 4, 2, 0>  : brnn_recurrent_t_kernel<8, 0, 2, 4, 2, 0>;  nldsf = 16; break;  // H = 512
-            case 64:  tk = one ? brnn_recurrent_t_kernel<16, 0, 1, 4, 2, 1> : brnn_recurrent_t_kernel<16, 0, 2, 4, 2, 1>; nldsf = 32; break;  // H = 1024
+            case 32:  tk = one ? brnn_recurrent_t_kernel<8, 0, 1, 4, 2, 0, 3>  : brnn_recurrent_t_kernel<8, 0, 2, 4, 2, 0, 3>;  nldsf = 16; break;  // H = 512
+            case 64:  tk = one ? brnn_recurrent_t_kernel<16, 0, 1, 4, 2, 1, 3> : brnn_recurrent_t_kernel<16, 0, 2, 4, 2, 1, 3>; nldsf = 32; break;  // H = 1024
             case 114:   // H = 1824
                 nldsf = 33;
-                if (one) tk = tcfg == 1 ? brnn_recurrent_t_kernel<29, 25, 1, 6, 3, 1> : brnn_recurrent_t_kernel<29, 25, 1, 8, 4, 1>;
-                else tk = tcfg == 1 ? brnn_recurrent_t_kernel<29, 25, 2, 6, 3, 1> : brnn_recurrent_t_kernel<29, 25, 2, 8, 4, 1>;
+                if (one) tk = tcfg == 1 ? brnn_recurrent_t_kernel<29, 25, 1, 6, 3, 1, 4> : tcfg == 2 ? brnn_recurrent_t_kernel<29, 25, 1, 8, 2, 1, 7>
+                              : brnn_recurrent_t_kernel<29, 25, 1, 8, 4, 1, 5>;
+                else tk = tcfg == 1 ? brnn_recurrent_t_kernel<29, 25, 2, 8, 4, 1, 5> : tcfg == 2 ? brnn_recurrent_t_kernel<29, 25, 2, 8, 2, 1, 7>
+                          : brnn_recurrent_t_kernel<29, 25, 2, 6, 3, 1, 4>;     // (8, 4: 128 ring registers, 28 of them parked in the other file)
                 break;
             case 128:   // H = 2048
                 nldsf = 33;
-                if (one) tk = tcfg == 1 ? brnn_recurrent_t_kernel<32, 31, 1, 6, 3, 1> : brnn_recurrent_t_kernel<32, 31, 1, 8, 4, 1>;
-                else tk = tcfg == 1 ? brnn_recurrent_t_kernel<32, 31, 2, 6, 3, 1> : brnn_recurrent_t_kernel<32, 31, 2, 8, 4, 1>;
+                if (one) tk = tcfg == 1 ? brnn_recurrent_t_kernel<32, 31, 1, 6, 3, 1, 4> : brnn_recurrent_t_kernel<32, 31, 1, 8, 4, 1, 5>;
+                else tk = tcfg == 1 ? brnn_recurrent_t_kernel<32, 31, 2, 6, 3, 1, 4> : brnn_recurrent_t_kernel<32, 31, 2, 8, 4, 1, 5>;
                 break;
             default: break;
         }

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-phase timeline of brnn_recurrent_t_kernel (SCTC_REC_DEBUG=1 stamps, 100 MHz wall clock): steps 64..71 of both
 sub-chains on the first and last unit block of combo 0, forward pass and BPTT.
-usage: tools/rec_tiled_timeline.py [B ...]   env H (1824)"""
+usage: tools/build_variant.sh stamps recurrent.hip -DSCTC_T_STAMPS      (or -DSCTC_T_STAMP_CHUNKS: one stamp per chunk as well)
+       SCTC_LIB_PATH=stanford-ctc_amd/libvar_stamps.so tools/rec_tiled_timeline.py [B ...]   env H (1824)
+(the production library has no stamps in this kernel: eight branches per phase cost it 0.1-0.2 us per phase)"""
 import ctypes
 import os
 import sys
@@ -47,6 +49,8 @@ for B in [int(v) for v in sys.argv[1:]] or [64, 128]:
     for ps, pname in enumerate(("forward", "bptt")):
         f = fine[ps, 0]
         n = int((f[0] != 0).sum())
+        if n < 4:         # the library was not built with -DSCTC_T_STAMP_CHUNKS
+            continue
         d = np.diff(f[:, :n], axis=1) * 0.01
         print("B=%d %s wg first, us per chunk (median of 8 phases), chunk 0 includes the phase's setup:" % (B, pname))
         print("     " + " ".join("%.2f" % v for v in np.median(d, axis=0)))
