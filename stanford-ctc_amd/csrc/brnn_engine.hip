@@ -354,9 +354,9 @@ static int make_plan(sctc_brnn* h, const sctc_minibatch* mb, bool need_labels, h
             while (na > 0 && h->Ts[na - 1] <= t) --na;
             h->nact[t] = na;
             h->rowbase[t] = (int32_t)base;
-            h->xbase[t] = (int32_t)xb;     // exchange rows: every step's block starts on 256 B
+            h->xbase[t] = (int32_t)xb;     // exchange rows: every step's block starts on 256 B (whole tiles from 17 utterances on)
             base += na;
-            xb += (na + 3) & ~3;
+            xb += recurrent_step_xrows(na);
         }
         h->n_xrows = xb;
     }

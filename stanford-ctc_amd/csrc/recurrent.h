@@ -29,7 +29,8 @@ struct RecArgs {
     float max_act;          // <= 0: no ceiling
     // Exchange buffer: chunk-major copy of the state, [2 groups][Hp/16][n_xrows][16] floats.
     // Exchange row of utterance b at STEP j = xbase[j] + b; xbase rounds every step's
-    // block up to 4 rows (256 B) so that no cache line holds data of two different steps.
+    // block up to 4 rows (256 B) so that no cache line holds data of two different steps,
+    // and up to 16 rows from 17 alive utterances on (recurrent_step_xrows below).
     float* xbuf;
     const int32_t* xbase;   // device [Tmax]
     int32_t n_xrows;
@@ -70,8 +71,13 @@ static constexpr int REC_DEBUG_WORDS = 2 * 16 * 8 + 512 * 8;
 static constexpr int REC_FLAG_STRIDE = SCTC_REC_FLAG_STRIDE;
 static constexpr int REC_COUNTER_WORDS = 32 + 4 * 128 * REC_FLAG_STRIDE;   // error word + up to 4 chains x 128 producers
 
-// exchange rows needed for `rows` frames spread over `tmax` time steps (worst case)
-static inline int64_t recurrent_xrows_bound(int64_t rows, int64_t tmax) { return rows + 3 * tmax; }
+// Exchange rows of a time step whose `alive` utterances are still running: a multiple of 4 (256 bytes: no cache line
+// holds data of two steps); from 17 utterances on a multiple of 16, so that every tile of 16 utterances that is alive at
+// all has its 16 rows inside the step's block and keeps the lane-order layout (recurrent.hip, lane_order_steps).
+static inline int recurrent_step_xrows(int alive) { return alive >= 17 ? (alive + 15) & ~15 : (alive + 3) & ~3; }
+// exchange rows needed for `rows` frames spread over `tmax` time steps (worst case: 3 rows of padding per step, 12 more
+// for each of the at most rows / 17 steps with 17 or more utterances alive)
+static inline int64_t recurrent_xrows_bound(int64_t rows, int64_t tmax) { return rows + 3 * tmax + 12 * (rows / 17 + 1); }
 size_t recurrent_xbuf_floats(int Hp, int64_t max_xrows);
 int recurrent_supported(int Hp, int B, char* why, int why_len);
 // which path a launch_recurrent call took (`path` out-parameter, nullable)

@@ -113,6 +113,21 @@ __device__ __forceinline__ float4 step_result(const float4& pre, const float4& s
     return o;
 }
 
+// For how many steps a tile of 16 utterances keeps its KB per chunk in LANE order ([k quarter][utterance][4 units]: a wave
+// access is one contiguous KB; row-major, [utterance][16 units], makes every 16-lane group of a load touch eight lines):
+// as long as the tile's 16 exchange rows all lie inside the step's block.  The engine (brnn_engine.hip, plan_minibatch)
+// rounds a step's block up to 16 rows from 17 alive utterances on and to 4 below -- so (round 6) every tile but the first
+// keeps lane order for its WHOLE life (while one of its utterances is alive more than 16 of the minibatch are), dead
+// slots simply stay unwritten; the first tile of the first launch while at least 13 utterances are alive (13..16 round up
+// to 16 rows).  Rounds 5: only while all 16 utterances of the tile were alive -- a ragged minibatch ran most of its steps
+// row-major (7.7 instead of 6.4 us per step at 32 utterances of T/2..T frames).
+// uT: the lengths of the tile's utterances, lane uj = utterance uj (0 beyond the minibatch); tile: launch-local index.
+__device__ __forceinline__ int lane_order_steps(int uT, int tile, int b_off, int variant)
+{
+    if (variant == 46) return 0;        // row-major throughout (rounds 1-5a; bit-identical A/B)
+    return (tile == 0 && b_off == 0) ? __builtin_amdgcn_readlane(uT, 12) : __builtin_amdgcn_readlane(uT, 0);
+}
+
 __device__ __forceinline__ float4 ld_x(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off,
                                        unsigned chunk_off)
 {
@@ -238,17 +253,11 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_kernel(RecArgs p)
         ub[i] = (ng + 2 * i) * 16 + uj;
         uT[i] = ub[i] < p.B ? p.T_b[ub[i]] : 0;
     }
-    // Steps at which all 16 utterances of a tile are alive (j < the tile's shortest length) keep the tile's 1 KB of a chunk
-    // as [k quarter][utterance][4 units]: lane l = uj + 16 kq then reads / writes byte 16 l, a wave one contiguous KB.  The
-    // row-major form ([utterance][16 units]: consecutive lanes 64 bytes apart, every 16-lane group of a load touching all
-    // eight lines) stays for a tile's last steps, whose missing rows belong to the next step's block.
+    // Steps at which a tile's 16 exchange rows lie inside the step's block (lane_order_steps above) keep the tile's 1 KB of a
+    // chunk as [k quarter][utterance][4 units]: lane l = uj + 16 kq then reads / writes byte 16 l, a wave one contiguous KB.
     int tile_T[NTW];
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        int m = 0x7fffffff;
-        for (int l = 0; l < 16; ++l) m = min(m, __builtin_amdgcn_readlane(uT[i], l));
-        tile_T[i] = p.variant == 46 ? 0 : m;       // 46: row-major throughout (rounds 1-5a; A/B)
-    }
+    for (int i = 0; i < NTW; ++i) tile_T[i] = lane_order_steps(uT[i], ng + 2 * i, p.b_off, p.variant);
     const int c_beg = kh * nch_half, c_end = c_beg + nch_half;
     // Which K half adds the other's partial sums to its own and stores the step's result of tile i.  Rounds 1-4: the
     // lower half, every tile (the upper half's waves sat out the epilogue: 1.8 us of a 128-utterance step).  Round 5:
@@ -529,11 +538,9 @@ __global__ __launch_bounds__(256, 2) void brnn_recurrent_q_kernel(RecArgs p)
     const int uT = ub < p.B ? p.T_b[ub] : 0;
     // this chain is finished once its longest utterance (the tile's first) is
     const int Tchain = tile * 16 < p.B ? p.T_b[tile * 16] : 0;
-    // exchange layout of the tile's KB per chunk: in lane order while all 16 utterances are alive (j < tile_T), row-major
-    // for the tile's last steps -- see brnn_recurrent_kernel above (round 5; SCTC_REC_VARIANT=46: row-major throughout)
-    int tile_T = 0x7fffffff;
-    for (int l = 0; l < 16; ++l) tile_T = min(tile_T, __builtin_amdgcn_readlane(uT, l));
-    if (p.variant == 46) tile_T = 0;
+    // exchange layout of the tile's KB per chunk: in lane order while its 16 rows lie inside the step's block (j < tile_T),
+    // row-major after that -- lane_order_steps above (SCTC_REC_VARIANT=46: row-major throughout)
+    const int tile_T = lane_order_steps(uT, tile, p.b_off, p.variant);
 
     const int dbg_sel = (p.debug && chain == 0 && tid == 0) ? (wg == 0 ? 0 : (wg == nwg - 1 ? 1 : -1)) : -1;
     auto stamp = [&](int j, int k) {
@@ -777,9 +784,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
             S.trow[i] = (unsigned)tile * 16u;
             S.ub[i] = tile * 16 + uj;
             S.uT[i] = S.ub[i] < p.B ? p.T_b[S.ub[i]] : 0;
-            int m = 0x7fffffff;
-            for (int l = 0; l < 16; ++l) m = min(m, __builtin_amdgcn_readlane(S.uT[i], l));
-            S.tile_T[i] = p.variant == 46 ? 0 : m;
+            S.tile_T[i] = lane_order_steps(S.uT[i], tile, p.b_off, p.variant);
             S.rb_next[i] = S.uT[i] > 0 ? p.rowbase[desc ? S.uT[i] - 1 : 0] : 0;
         }
         S.T = __builtin_amdgcn_readfirstlane((int)S.trow[0] < p.B ? p.T_b[S.trow[0]] : 0);
