@@ -840,6 +840,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
             xin[i] = prow * 64u + (unsigned)kq * 16u;
             if (j > 0 && j <= S.tile_T[i] && active)       // the tile was complete at step j - 1: lane order
                 xin[i] = (xb_prev + S.trow[i]) * 64u + (unsigned)lane * 16u;
+            if (p.variant == 49) xin[i] = (unsigned)lane * 16u;     // DIAGNOSTIC (wrong results): every load re-reads step 0's rows -- lines that stay cached -- to time the kernel without the arrival of fresh exchange data
         }
     };
     // batch bi of a phase into ring slot bi % R
@@ -1042,15 +1043,27 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[ug][i][q] = {0.f, 0.f, 0.f, 0.f};
 
+        // The LDS-resident weight fragments are read WA groups ahead of the MFMAs that take them (a rotating set of
+        // WA + 1 registers quadruples): read in front of its use, a fragment costs its group the LDS round trip -- measured
+        // 0.28-0.32 us for a chunk with LDS weights against 0.24 with register weights, 1 us per phase, with every exchange
+        // load served from cache (SCTC_REC_VARIANT=49: same times -- it was never the exchange data).
+        constexpr int WA = 2;
+        float4 aq[WA + 1];
+        auto prefetch_a = [&](auto G_c) {      // G: group index within the phase = chunk * NC + result
+            constexpr int G = decltype(G_c)::value, cu = G / NC, f = 2 * cu + ((G % NC) & 1);
+            if constexpr (cu < NCQ && f >= NREGF) aq[G % (WA + 1)] = Wl[(f - NREGF) * 64 + lane];
+        };
         // four MFMAs: chunk u of batch bi, result g = 2 * tile slot + unit group
         auto mfma_group = [&](auto bi_c, auto u_c, auto g_c) {
             constexpr int bi = decltype(bi_c)::value, u = decltype(u_c)::value, cu = bi * XB + u;
             constexpr int gi = decltype(g_c)::value >> 1, ug = decltype(g_c)::value & 1;
+            constexpr int G = cu * NC + decltype(g_c)::value;
+            prefetch_a(std::integral_constant<int, G + WA>());
             if constexpr (cu < NCQ) {
                 if (cu < NCQ - 1 || cnt == NCQ) {     // the last chunk exists only in the longer waves
                     constexpr int f = 2 * cu + ug;
                     float4 a;
-                    if constexpr (f < NREGF) a = wreg[f]; else a = Wl[(f - NREGF) * 64 + lane];
+                    if constexpr (f < NREGF) a = wreg[f]; else a = aq[G % (WA + 1)];
                     SCTC_MFMA4(acc[ug][gi], a, x[bi % R][u][gi])
                 }
             }
@@ -1075,6 +1088,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
                 if constexpr (cu < NCQ)
                     x[bi % R][u][i] = ld_x(xrsrc, xs[i], (unsigned)(c_beg + min(cu, cnt - 1)) * chunk_stride);
             };
+            static_for<WA>([&](auto G_c) { prefetch_a(G_c); });
             static_for<NBAT>([&](auto b_c) {
                 constexpr int b = decltype(b_c)::value;
                 constexpr int nb = b + R - 1;       // the batch whose loads are issued between batch b's MFMAs
