@@ -49,8 +49,9 @@ struct RecArgs {
                             // 43: the sentinel / VALU kernel for up to 8 utterances (default: up to 3); 44: the single-chain
                             //     flag kernel from 1 utterance (default: from 4)
                             // 46: exchange tiles row-major throughout (rounds 1-5a; bit-identical A/B of the lane-order layout);
-                            // 47: more than 32 utterances on the one-slab-per-CU kernel of rounds 1-5 (default since round 6 where the
-                            //     layer size has it: units x utterances, brnn_recurrent_t_kernel)
+                            // 47: more than 32 utterances on the one-slab-per-CU kernel of rounds 1-5 (default since round 6 at 1824 / 2048
+                            //     units: units x utterances, brnn_recurrent_t_kernel); 50: the tiled kernel at 512 / 1024 units as well
+                            //     (no faster there; tests); 49: DIAGNOSTIC, wrong results -- the tiled kernel re-reads step 0's exchange rows
     unsigned* debug;        // nullable: s_memtime stamps [2 wgs][16 steps][8] for steps 64..79
     int32_t b_off;          // rank of this launch's first utterance in the packed minibatch (minibatches of
                             // more than 128 utterances run as several launches; T_b already points at it)

@@ -744,16 +744,22 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
     // file): together with the exchange ring they would not fit the 256 architectural registers, and what the
     // compiler then parks in the other file it copies back through a waited-for load -- the prefetch is gone.
     float4 wreg[NREGF > 0 ? NREGF : 1];
+    // (a wave whose K quarter has one chunk less than NCQ multiplies that chunk too, with ZERO weights: + 0 exactly, and
+    // the MFMA stream has no branch -- a branch around the last chunk's MFMAs cost 0.24 us per phase in waits at its join)
+    auto load_w0 = [&](int f) {
+        const float4 w = load_w(c_beg + min(f >> 1, cnt - 1), f & 1);
+        return (f >> 1) < cnt ? w : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
 #pragma unroll
     for (int f = 0; f < NREGF; ++f) {
-        const float4 w = load_w(c_beg + min(f >> 1, cnt - 1), f & 1);
+        const float4 w = load_w0(f);
         asm("v_accvgpr_write_b32 %0, %1" : "=a"(wreg[f].x) : "v"(w.x));
         asm("v_accvgpr_write_b32 %0, %1" : "=a"(wreg[f].y) : "v"(w.y));
         asm("v_accvgpr_write_b32 %0, %1" : "=a"(wreg[f].z) : "v"(w.z));
         asm("v_accvgpr_write_b32 %0, %1" : "=a"(wreg[f].w) : "v"(w.w));
     }
 #pragma unroll 4
-    for (int f = NREGF; f < NFR; ++f) Wl[(f - NREGF) * 64 + lane] = load_w(c_beg + min(f >> 1, cnt - 1), f & 1);
+    for (int f = NREGF; f < NFR; ++f) Wl[(f - NREGF) * 64 + lane] = load_w0(f);
     __syncthreads();
 
     const bool desc = p.descending[g] != 0;
@@ -1060,12 +1066,10 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
             constexpr int G = cu * NC + decltype(g_c)::value;
             prefetch_a(std::integral_constant<int, G + WA>());
             if constexpr (cu < NCQ) {
-                if (cu < NCQ - 1 || cnt == NCQ) {     // the last chunk exists only in the longer waves
-                    constexpr int f = 2 * cu + ug;
-                    float4 a;
-                    if constexpr (f < NREGF) a = wreg[f]; else a = aq[G % (WA + 1)];
-                    SCTC_MFMA4(acc[ug][gi], a, x[bi % R][u][gi])
-                }
+                constexpr int f = 2 * cu + ug;
+                float4 a;
+                if constexpr (f < NREGF) a = wreg[f]; else a = aq[G % (WA + 1)];
+                SCTC_MFMA4(acc[ug][gi], a, x[bi % R][u][gi])
             }
         };
         auto mfma_chunk = [&](auto bi_c, auto u_c) {
@@ -2666,7 +2670,10 @@ static int launch_recurrent_one(const RecArgs& a, const LaunchCtx& cx)
     }
     // 33..128 utterances: 32 units x half the utterance tiles per CU, two alternating sub-chains (round 6);
     // variants 1 / 40 / 47 keep the one-slab-per-CU kernel below
-    if (ntiles > 2 && a.variant != 1 && a.variant != 40 && a.variant != 47 && 4 * (a.Hp / 32) <= cx.cus) {
+    // (H = 512 / 1024: 64 / 128 workgroups, no faster than the one-slab-per-CU kernel on as many CUs -- 9.3 against 8.4 us per
+    // step at H = 1024, 64 utterances: there the tiled form runs only when asked for, SCTC_REC_VARIANT=50: tests)
+    if (ntiles > 2 && a.variant != 1 && a.variant != 40 && a.variant != 47 && 4 * (a.Hp / 32) <= cx.cus &&
+        (a.Hp >= 1824 || a.variant == 50)) {
         RecKernel tk = nullptr;
         const bool one = ntiles <= 4;       // one utterance tile per sub-chain
         int nldsf = 0;
@@ -2746,7 +2753,8 @@ int launch_recurrent(const RecArgs& a_in, hipStream_t stream, int* path)
         // 32 + the rest, round 5's cut); 65..96 as 64 + the rest (72 / 80: 15.0 against 18.7 in one launch of the two-tile
         // form, which multiplies its empty tile slots; 96 = 64 + 32: 9.5 + 6.4); 97..128 in one launch (18.7).
         // Variant 45: never cut.  Kernels without the tiled form (variants 1 / 40 / 47, other layer sizes) keep round 5's cuts.
-        const bool tiled = a.variant == 0 && !a.prec16 && (a.Hp == 512 || a.Hp == 1024 || a.Hp == 1824 || a.Hp == 2048) && 4 * (a.Hp / 32) <= cx.cus;
+        const bool tiled = ((a.variant == 0 && (a.Hp == 1824 || a.Hp == 2048)) || (a.variant == 50 && (a.Hp == 512 || a.Hp == 1024 || a.Hp == 1824 || a.Hp == 2048))) &&
+                           !a.prec16 && 4 * (a.Hp / 32) <= cx.cus;
         if (tiled) {
             if (nb > 64 && nb <= 96) nb = 64;
         } else {
