@@ -994,11 +994,6 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
         constexpr bool FIRST = decltype(first_c)::value;     // step 0, known at compile time: the time loop's copy has one path
         stamp(sub, j, 0);
         stamp_chunk(sub, j, 0);
-        const unsigned xb_prev = S.xb_cur, xb_cur = S.xb_next;
-        S.xb_cur = xb_cur;
-        int rb[NT];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) rb[i] = S.rb_next[i];
         // The loads whose results are needed LATER -- the next step's xbase / rowbase, this step's additive term (its
         // epilogue runs inside the next phase) -- are issued behind the first batches, not here: anything loaded at the
         // head of the phase ends up being waited for inside batch 0 together with the exchange ring.
@@ -1015,10 +1010,18 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
             en.pre4 = *reinterpret_cast<const float4*>(pre + en.out_off);
             en.act4 = *reinterpret_cast<const float4*>(act_or_pre + en.out_off);
         };
+        // The phase's addresses: exchange offsets of its own later batches, what this wave's epilogue needs (result c = wave:
+        // tile slot c >> 1, unit group c & 1).  Nothing the first MFMAs take (their batch is in flight, the weights are there):
+        // computed BEHIND the first group of four, under the matrix pipe, not in front of it.
         unsigned xin[NT];
-        xin_of(S, j, xb_prev, xin);
-        // what this wave's epilogue needs (result c = wave: tile slot c >> 1, unit group c & 1)
         Epi En;
+        auto setup = [&]() {
+        const unsigned xb_prev = S.xb_cur, xb_cur = S.xb_next;
+        S.xb_cur = xb_cur;
+        int rb[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) rb[i] = S.rb_next[i];
+        xin_of(S, j, xb_prev, xin);
         En.pending = true;
         En.zero = FIRST;
         En.parity = phase_no & 1;
@@ -1040,7 +1043,8 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
                 En.out_off = orow * ld + row0 + 16 * (wave & 1) + 4 * kq;
             }
         }
-        if constexpr (FIRST) late_loads(En);
+        };
+        if constexpr (FIRST) { setup(); late_loads(En); }
         f32x4 acc[2][NT][4];
 #pragma unroll
         for (int ug = 0; ug < 2; ++ug)
@@ -1116,6 +1120,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
                     constexpr int s = decltype(s_c)::value;
                     mfma_group(b_c, std::integral_constant<int, s / NC>(), std::integral_constant<int, s % NC>());
                     __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (b == 0 && s == 0) { setup(); __builtin_amdgcn_sched_barrier(0); }
                     if constexpr (s % NC == NC - 1) stamp_chunk(sub, j, 1 + b * XB + s / NC);
                     if constexpr (b == 0) {
                         if constexpr (s % NC == NC - 1 && s / NC < 5) stamp(sub, j, 1 + s / NC);
