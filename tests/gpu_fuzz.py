@@ -34,7 +34,7 @@ def run(n_cases=40, seed=0):
     worst = 0.0
     for case in range(n_cases):
         H = int(rs.choice([512, 512, 1024, 1824, 2048, 96]))
-        B = int(rs.choice([1, 2, 3, 4, 5, 6, 8, 11, 16, 17, 24, 32, 33, 40]))
+        B = int(rs.choice([1, 2, 3, 4, 5, 6, 8, 11, 16, 17, 24, 32, 33, 40, 48, 64, 65, 81, 100, 128]))   # (round 6: beyond 40 -- the tiled kernel, the launch cuts)
         NL = int(rs.choice([2, 3]))
         TL = int(rs.randint(1, NL))
         D, A = 24, int(rs.choice([33, 62]))
