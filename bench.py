@@ -132,7 +132,9 @@ def cpu_baseline(cfg, budget_s=75.0):
     finally:
         _CPU_CTX = None
     best = max(tried)
-    return {"value": best[0], "unit": "frames/s", "cores": best[1] * best[2], "kind": "port",
+    return {"value": best[0], "unit": "frames/s", "cores": best[1] * best[2],
+            "kind": "port, extrapolated from T=%d utterances (the like-for-like T=%d figure is single_thread: %.0f frames/s on one core)"
+                    % (best[5], cfg["T"], single["value"]),
             "host_cores": ncpu,
             "sample": "best of a sweep over processes x BLAS threads on the %d host cores: %d utterances "
                       "of T=%d (cfg-3 shape, a fraction of the headline length) in %d processes x %d "
