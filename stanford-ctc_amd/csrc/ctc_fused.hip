@@ -93,9 +93,31 @@ struct __attribute__((aligned(sizeof(ST) * K))) RowBlockA {
 
 }  // namespace
 
+// The two-wave form on float32 probabilities with 32-bit rows, up to 4 states per lane, up to 64 symbols (the
+// saturating-batch form of BASELINE configs[0..2]) goes on a REGISTER DIET (round 6): SQ counters showed
+// the SIMDs 0.64 VALU-busy with two waves each (194 registers), a third wave needs <= 168.  Three things: list entries
+// 8..15 of a label are not kept in registers (NI2 = NI: the slow path beyond 8 reads them from LDS), the label products
+// of a finished block are not fetched ahead of the transposed sums (EARLY: 64 registers at the peak), and the
+// compiler is told the occupancy to aim for (amdgpu_waves_per_eu; 4 spill slots outside the frame loop at 4 states
+// per lane, none at 2 -- 116 registers: four waves).
+// Measured (tools/ab_ctc_diet.sh, both libraries in alternation on one box, events around the C entry): 4096 utterances of
+// the cfg-3 shape 4.43-4.52 ms against 4.72-4.86 (-6 %), 1024 utterances 1.27 against 1.23 (+3 %: two waves per SIMD
+// either way, and the dieted code is a little slower) -- so it is its own instantiation, taken from 1537 utterances on.
 template <typename RI, typename ST, int K, int NA, bool HELP>
-__global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArgs<RI> p)
+struct FusedDiet {
+#ifdef SCTC_FUSED_NO_DIET       // A/B build (tools/build_variant.sh nodiet ctc_fused.hip -DSCTC_FUSED_NO_DIET)
+    static constexpr bool possible = false;
+#else
+    static constexpr bool possible = !HELP && NA == 1 && K <= 4 && sizeof(RI) == 4 && sizeof(ST) == 4;
+#endif
+};
+static constexpr int FUSED_DIET_MIN_B = 1537;
+
+template <typename RI, typename ST, int K, int NA, bool HELP, bool DIET = false>
+__global__ __launch_bounds__(HELP ? 384 : 128) __attribute__((amdgpu_waves_per_eu(DIET ? 3 : 1, 8)))
+void ctc_fused_kernel(CtcFusedArgs<RI> p)
 {
+    static_assert(!DIET || FusedDiet<RI, ST, K, NA, HELP>::possible, "the dieted form exists for the two-wave float32 / 32-bit-row kernel of up to 4 states per lane only");
     using R = double;
     static_assert(K == 2 || K == 4 || K == 8, "one wave per direction: 2, 4 or 8 states per lane (rows of up to 512 states)");
     constexpr int KH = K / 2;
@@ -107,7 +129,7 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
     // utterances; it is the form of the batches that fill the device)
     constexpr int PF = HELP ? (K == 8 ? 4 : 8) : SCTC_FUSED_PF2;
     constexpr int NI = NA == 1 ? 8 : 4;     // list entries of a label summed unconditionally
-    constexpr int NI2 = NA == 1 ? 16 : NI;  // list entries kept in registers (those beyond NI: summed when some list is that long)
+    constexpr int NI2 = (NA == 1 && !DIET) ? 16 : NI;  // list entries kept in registers (those beyond NI: summed when some list is that long)
     constexpr int NPOS = 64 * KH;           // label positions of one direction; slot NPOS holds 0.0
     constexpr int LSTR = NPOS + 2;
     constexpr int RSTR = (HELP && K == 2) ? 64 : 66;   // row stride of the reduction scratch (bank spread where it fits)
@@ -429,7 +451,7 @@ __global__ __launch_bounds__(HELP ? 384 : 128) void ctc_fused_kernel(CtcFusedArg
         static_assert(NF <= FS && (NF == 8 || NF == 4), "one lane per (sum, part)");
         // the label products of the frames' slots: where they fit into registers they are fetched first and return
         // while the sums cross LDS
-        constexpr bool EARLY = NF * NA * NI <= 32;
+        constexpr bool EARLY = !DIET && NF * NA * NI <= 32;
         R lv[EARLY ? NF : 1][EARLY ? NA : 1][NI];
         if constexpr (EARLY) {
 #pragma unroll
@@ -906,6 +928,14 @@ static int launch_fused_one(const CtcFusedArgs<RI>& a, int B, hipStream_t stream
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         });
         SCTC_HIP_TRY(attr);
+    }
+    if constexpr (FusedDiet<RI, ST, K, NA, HELP>::possible) {
+        const char* dz = getenv("SCTC_CTC_DIET_MIN_B");      // tests / A/B: the dieted form from this many utterances on
+        if (B >= (dz ? atoi(dz) : FUSED_DIET_MIN_B)) {
+            hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, NA, HELP, true>), grid, block, dyn, stream, a);
+            SCTC_HIP_TRY(hipGetLastError());
+            return SCTC_OK;
+        }
     }
     hipLaunchKernelGGL((ctc_fused_kernel<RI, ST, K, NA, HELP>), grid, block, dyn, stream, a);
     SCTC_HIP_TRY(hipGetLastError());

@@ -32,8 +32,10 @@ def mods():
 class path:
     """context manager: force one CTC path through the environment switches the plan reads per call"""
     ENV = {"fused": {}, "fused64": {"SCTC_CTC_STORE": "64"}, "fused2w": {"SCTC_CTC_HELPER": "0"},
+           # round 6: the two-wave form on its register diet (three waves per SIMD; by default from 1537 utterances on)
+           "fused2wd": {"SCTC_CTC_HELPER": "0", "SCTC_CTC_DIET_MIN_B": "1"},
            "lattice": {"SCTC_CTC_FUSED": "0"}, "generic": {"SCTC_CTC_GENERIC": "1"}}
-    VARS = ("SCTC_CTC_STORE", "SCTC_CTC_FUSED", "SCTC_CTC_GENERIC", "SCTC_CTC_HELPER")
+    VARS = ("SCTC_CTC_STORE", "SCTC_CTC_FUSED", "SCTC_CTC_GENERIC", "SCTC_CTC_HELPER", "SCTC_CTC_DIET_MIN_B")
 
     def __init__(self, name):
         self.env = self.ENV[name]
@@ -186,7 +188,7 @@ def test_fused_f32_row_store(mods):
         with np.errstate(all="ignore"):
             c_ref, g_ref, s_ref = octc.ctc_loss(np.asfortranarray(y.astype(np.float64)), seq)
         res = {}
-        for which in ("fused", "fused64", "fused2w", "lattice"):
+        for which in ("fused", "fused64", "fused2w", "fused2wd", "lattice"):
             with path(which), np.errstate(all="ignore"):
                 cost, grads, skip = cf.ctc_loss_batch([y], [seq])
             assert not skip[0] and not s_ref
@@ -218,7 +220,7 @@ def test_fused_ragged_batch_and_long_lists(mods):
         for b in range(37):
             with np.errstate(all="ignore"):
                 refs.append(octc.ctc_loss(np.asfortranarray(probs[b].astype(np.float64)), seqs[b]))
-        for which in ("fused", "fused2w"):
+        for which in ("fused", "fused2w", "fused2wd"):
             with path(which), np.errstate(all="ignore"):
                 cost, grads, skip = cf.ctc_loss_batch(probs, seqs)
             for b in range(37):
