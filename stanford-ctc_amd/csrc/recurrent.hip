@@ -1212,301 +1212,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
 }
 
 #ifdef SCTC_REC_EXPERIMENTS    // measured slower / superseded kernels, kept for the A/Bs of profiles/r04_recurrence_q8.md and r05 (build with -DSCTC_REC_EXPERIMENTS)
-// ---------------------------------------------------------------------------------------
-// Both chains of a direction in ONE workgroup (17..32 utterances; round 4).  The two-chain kernel
-// above leaves the pairing of chains on a compute unit to the dispatcher: 200 CUs hold two
-// workgroups, 56 hold one, the workgroups that share need 5.1 us from "flags seen" to "published"
-// against 3.8 us for the ones that do not, and every chain waits for its slowest producer.  Here a
-// workgroup of EIGHT waves owns 16 output units of one direction and serves BOTH utterance tiles:
-// waves 0..3 = tile 0, waves 4..7 = tile 1 (4 K quarters each; wave w and wave w + 4 share a SIMD).
-// One workgroup per CU, 2 * Hp/16 CUs (228 at H = 1824), every CU in the same situation.
-//   * ONE copy of the 16 x H weight slab, all of it in LDS (114 KiB at H = 1824, fragment order):
-//     no weight registers, and the two tiles read the same fragments.
-//   * The two chains stay independent: nothing inside the time loop is a workgroup barrier.  The
-//     four waves of a tile hand over through LDS words -- "go" (the polling wave has seen all flags
-//     of step j), "done" (a wave's partial sums of step j are in LDS) -- written with plain
-//     ds_write and polled with ds_read; the LDS executes one wave's instructions in order, so a
-//     payload written before its word is visible before it.
-//   * Chain-level tokens (mode bits 0 / 1).  Measured (round 4, profiles/r04_recurrence_q8.md): treated
-//     alike, the two chains of a CU run IN PHASE -- both see their flags within 0.5 us of each other,
-//     their 2 x 116 KiB of exchange loads interleave in the CU's one vector-memory pipeline, their
-//     MFMA bursts interleave on the matrix pipes, both finish late and publish together -- and a
-//     symmetric collision leaves the phase where it was.  The tokens make a collision ASYMMETRIC:
-//     the chain that comes first runs as if it were alone, the other one waits its turn, and is
-//     thereby pushed half a step behind, where the two no longer meet.
-//       M token: a signed count in LDS (+k: k waves of tile 0 are inside their MFMA burst, -k: of
-//                tile 1); a wave enters when its first exchange load has returned and the count
-//                does not belong to the other tile.
-//       L token: the polling wave takes it before it says "go" and the chain's last wave returns it
-//                when all exchange loads of the step have been issued: the loads of one chain are
-//                contiguous in the vector-memory queue.
-// The K split, the order of the MFMAs and of every addition are those of the two-chain kernel:
-// results are bit-identical (tests/gpu_ab_rec.py is the acceptance gate).
-// mode (RecArgs.variant - 8): bit 0 M token, bit 1 L token, bit 2 no pacing sleep between exchange
-// loads, bit 4 tile 0's waves at issue priority 3.
-__device__ __forceinline__ unsigned lds_word_get(const unsigned* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_word_put(unsigned* p, unsigned v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-static constexpr int Q8_SYNC_WORDS = 16;    // go[2], done[2][3], M token, L token, L count[2], spare
-#ifndef SCTC_REC_Q8_DEFAULT
-#define SCTC_REC_Q8_DEFAULT 0               // 0: the two-workgroups-per-CU kernel stays the default
-#endif
-static constexpr int REC_Q8_DEFAULT = SCTC_REC_Q8_DEFAULT;
-template <int NCQ>
-__global__ __launch_bounds__(512, 1) void brnn_recurrent_q8_kernel(RecArgs p)
-{
-    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = wave >> 2, kw = wave & 3;
-    const int Hp = p.Hp, nch = Hp >> 4, nwg = nch;
-    const int mode = p.variant - 8;
-    const bool tok_m = (mode & 1) != 0, tok_l = (mode & 2) != 0;
-    const bool pace = (mode & 4) == 0, prio = (mode & 16) != 0;
-    // Block -> (direction, producer).  Workgroups are dealt to XCDs round-robin (block b runs on
-    // XCD b % 8): direction 0 lives on XCDs 0..3, direction 1 on XCDs 4..7, so an XCD's L2 fetches
-    // the exchanged state of two chains (both tiles of one direction).  The grid is rounded up to
-    // whole rounds of 8; the spare workgroups leave at once.  Placement only affects speed.
-    const int g = (blockIdx.x & 7) >> 2, wg = (blockIdx.x >> 3) * 4 + (blockIdx.x & 3);
-    if (wg >= nwg) return;
-    const int chain = 2 * tile + g;
-    const int row0 = wg * 16;
-    const int uj = lane & 15, kq = lane >> 4;
-    const int sync_mode = p.sync_mode;
-    const int base = nch >> 2, rem = nch & 3;
-    const int cnt = base + (kw < rem ? 1 : 0);
-    const int c_beg = kw * base + min(kw, rem);
-    float4* Wl = lds4;                                             // [nch][64] fragment order
-    float4* red = lds4 + (size_t)nch * 64 + (size_t)tile * 3 * 64; // this tile's [3][64] partial sums
-    unsigned* sw = reinterpret_cast<unsigned*>(lds4 + (size_t)nch * 64 + 6 * 64);
-    unsigned* go = sw + tile;
-    unsigned* done = sw + 2 + 3 * tile;
-    int* mtok = reinterpret_cast<int*>(sw + 8);
-    unsigned* ltok = sw + 9;
-    unsigned* lcnt = sw + 10 + tile;
-
-    // ---- stationary weights: fragment of chunk c = { Wop[row0 + (lane&15)][16c + 4*(lane>>4) + q] }_q
-    {
-        const float* W = p.W[g];
-        for (int c = wave; c < nch; c += 8) {
-            float4 v;
-            if (!p.transpose) {
-                v = *reinterpret_cast<const float4*>(W + (int64_t)(row0 + uj) * p.ldw + 16 * c + 4 * kq);
-            } else {
-                const float* col = W + (int64_t)(16 * c + 4 * kq) * p.ldw + row0 + uj;
-                v.x = col[0];
-                v.y = col[p.ldw];
-                v.z = col[2 * p.ldw];
-                v.w = col[3 * p.ldw];
-            }
-            Wl[c * 64 + lane] = v;
-        }
-        if (tid < Q8_SYNC_WORDS) sw[tid] = 0u;
-    }
-    __syncthreads();
-
-    const bool desc = p.descending[g] != 0;
-    const float* pre = p.pre[g];
-    const float* act = p.act[g];
-    float* out = p.out[g];
-    const int64_t ld = p.ld;
-    const float hi = p.max_act > 0.f ? p.max_act : INFINITY;
-    unsigned* flags = p.counters + 32 + chain * 128 * REC_FLAG_STRIDE;
-    unsigned* err = p.counters + 2;
-    const unsigned chunk_stride = (unsigned)p.n_xrows * 64u;
-    float* xg = p.xbuf + (size_t)g * p.n_xrows * Hp;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        xg, 0, (int)((size_t)p.n_xrows * Hp * sizeof(float)), 0x00020000);
-
-    const int ub = tile * 16 + uj;
-    const int uT = ub < p.B ? p.T_b[ub] : 0;
-    const int Tchain = tile * 16 < p.B ? p.T_b[tile * 16] : 0;
-
-    const int dbg_sel = (p.debug && chain == 0 && kw == 0 && lane == 0) ? (wg == 0 ? 0 : (wg == nwg - 1 ? 1 : -1)) : -1;
-    auto stamp = [&](int j, int k) {
-        if (dbg_sel >= 0 && j >= 64 && j < 80)
-            p.debug[(dbg_sel * 16 + (j - 64)) * 8 + k] = (unsigned)clock64();
-        if (p.debug && kw == 0 && lane == 0 && j == 70) {   // every chain of every workgroup: 100 MHz clock
-            const int slot = (blockIdx.x * 2 + tile) & 511;
-            p.debug[REC_DEBUG_ALL_OFF + slot * 8 + k] = (unsigned)wall_clock64();
-            if (k == 0) p.debug[REC_DEBUG_ALL_OFF + slot * 8 + 7] = 1u + (unsigned)chain;
-        }
-    };
-
-    // Static priority (mode bit 4): the two chains of a CU lock IN PHASE when they are treated alike -- they
-    // meet on the matrix pipe, both finish late, both publish at the same time, and meet again at the
-    // next step.  With tile 0's waves at a higher issue priority chain 0 runs as if it had the CU to
-    // itself and chain 1 takes the slots chain 0 leaves (its exchange-load latency, its epilogue and
-    // publish, its wait for the flags): once chain 1 has been pushed behind chain 0 it stays there.
-    if (prio && tile == 0) __builtin_amdgcn_s_setprio(3);
-    int rb_next = uT > 0 ? p.rowbase[desc ? uT - 1 : 0] : 0;
-    int xb_next = p.xbase[0], xb_cur = 0;
-    for (int j = 0; j < Tchain; ++j) {
-        stamp(j, 0);
-        f32x4 acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = {0.f, 0.f, 0.f, 0.f};
-        const bool active = j < uT;
-        const int xb_prev = xb_cur;
-        const int rb = rb_next;
-        xb_cur = xb_next;
-        {
-            const int jn = min(j + 1, Tchain - 1);
-            const int tn = desc ? uT - 1 - jn : jn;
-            rb_next = p.rowbase[min(max(tn, 0), p.Tmax - 1)];
-            xb_next = p.xbase[jn];
-        }
-        const int64_t orow = active ? (int64_t)rb + p.b_off + ub : 0;
-        const unsigned xrow = active ? (unsigned)xb_cur + (unsigned)ub : 0u;
-        const unsigned prow = (active && j > 0) ? (unsigned)xb_prev + (unsigned)ub : 0u;
-        const unsigned xin = prow * 64u + (unsigned)kq * 16u;
-        const unsigned xout = xrow * 64u + (unsigned)kq * 16u;
-        float4 pre4 = make_float4(0.f, 0.f, 0.f, 0.f), act4 = pre4;
-        if (kw == 0 && active) {
-            pre4 = *reinterpret_cast<const float4*>(pre + orow * ld + row0 + 4 * kq);
-            if (act) act4 = *reinterpret_cast<const float4*>(act + orow * ld + row0 + 4 * kq);
-        }
-
-        if (j > 0) {
-            // ---- step hand-off: all producers of this chain have published step j
-            if (kw == 0) {
-                const unsigned long long t0 = wall_clock64();
-                unsigned spins = 0;
-                first_poll_delay(p.poll_delay);
-                for (;;) {
-                    unsigned f0 = (unsigned)j, f1 = (unsigned)j;
-                    if (lane < nwg)
-                        f0 = __hip_atomic_load(flags + lane * REC_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (lane + 64 < nwg)
-                        f1 = __hip_atomic_load(flags + (lane + 64) * REC_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all(f0 >= (unsigned)j && f1 >= (unsigned)j)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((++spins & 255u) == 0) {
-                        if (spin_expired(err, t0, lane)) break;
-                    }
-                }
-                if (tok_l) {
-                    for (;;) {
-                        unsigned old = 1u;
-                        if (lane == 0) old = __hip_atomic_exchange(ltok, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (__builtin_amdgcn_readfirstlane(old) == 0u) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-                if (lane == 0) lds_word_put(go, (unsigned)j);
-            } else {
-                while (lds_word_get(go) < (unsigned)j) __builtin_amdgcn_s_sleep(1);
-            }
-            stamp(j, 1);
-            float4 x[NCQ];
-#pragma unroll
-            for (int u = 0; u < NCQ; ++u) {
-                x[u] = ld_x(xrsrc, xin, (unsigned)(c_beg + min(u, cnt - 1)) * chunk_stride);
-                __builtin_amdgcn_sched_barrier(0);
-                if (pace) __builtin_amdgcn_s_sleep(1);   // leaves the SIMD's issue slots to the other tile's wave
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_sched_barrier(0);   // every load ahead of the first MFMA
-            if (tok_l) {   // this wave's loads are in the queue; the chain's last wave hands the L token on
-                unsigned old = 0u;
-                if (lane == 0) old = __hip_atomic_fetch_add(lcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (__builtin_amdgcn_readfirstlane(old) == 3u && lane == 0) {
-                    lds_word_put(lcnt, 0u);
-                    lds_word_put(ltok, 0u);
-                }
-            }
-            if (tok_m) {
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NCQ - 1) : "memory");   // first exchange load is back
-                const int mine = tile == 0 ? 1 : -1;
-                for (;;) {
-                    int got = 0;
-                    if (lane == 0) {
-                        int old = __hip_atomic_load(mtok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (old * mine >= 0)
-                            got = __hip_atomic_compare_exchange_strong(mtok, &old, old + mine, __ATOMIC_RELAXED,
-                                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 2;
-                    }
-                    got = __builtin_amdgcn_readfirstlane(got);
-                    if (got == 1) break;
-                    if (got == 0) __builtin_amdgcn_s_sleep(1);       // the other tile's burst: wait; (2: lost a race, retry)
-                }
-                // the burst starts behind the token: its first four MFMAs read x[0] through this statement
-                asm volatile("" : "+v"(x[0].x), "+v"(x[0].y), "+v"(x[0].z), "+v"(x[0].w) :: "memory");
-            }
-            // weight fragments come from LDS two chunks ahead of their MFMAs: a ds_read_b128 issued behind
-            // the four MFMAs of the chunk before it leaves the matrix pipe idle for most of its latency
-            const float4* wfrag = Wl + (size_t)c_beg * 64 + lane;
-            float4 a0 = wfrag[0], a1 = wfrag[NCQ > 1 ? 64 : 0];
-#pragma unroll
-            for (int u = 0; u < NCQ; ++u) {
-                const float4 a2 = wfrag[(u + 2 < NCQ ? u + 2 : NCQ - 1) * 64];   // (a wave with NCQ - 1 chunks reads its neighbour's first: unused)
-                __builtin_amdgcn_sched_barrier(0);
-                if (u < NCQ - 1 || cnt == NCQ) {   // the last chunk exists only in the longer waves
-                    SCTC_MFMA4(acc, a0, x[u])
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                a0 = a1;
-                a1 = a2;
-            }
-            if (tok_m) {
-                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) :: "memory");
-                if (lane == 0)
-                    (void)__hip_atomic_fetch_add(mtok, tile == 0 ? -1 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (p.debug) {
-                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-                stamp(j, 2);
-            }
-            if (kw != 0) {
-                const f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-                red[(kw - 1) * 64 + lane] = make_float4(s[0], s[1], s[2], s[3]);
-                asm volatile("" ::: "memory");           // payload before its word (the LDS keeps a wave's order)
-                if (lane == 0) lds_word_put(done + (kw - 1), (unsigned)j);
-            } else {
-                for (;;) {
-                    unsigned v = (unsigned)j;
-                    if (lane < 3) v = lds_word_get(done + lane);
-                    if (__all(v >= (unsigned)j)) break;
-                }
-                asm volatile("" ::: "memory");
-            }
-            stamp(j, 3);
-        }
-
-        if (kw == 0 && active) {
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j > 0) {
-                const float4 r1 = red[lane], r2 = red[64 + lane], r3 = red[128 + lane];
-                const f32x4 q = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-                s = make_float4((q[0] + r1.x) + (r2.x + r3.x), (q[1] + r1.y) + (r2.y + r3.y),
-                                (q[2] + r1.z) + (r2.z + r3.z), (q[3] + r1.w) + (r2.w + r3.w));
-            }
-            const float4 o = step_result(pre4, s, act4, act != nullptr, hi);
-            *reinterpret_cast<float4*>(out + orow * ld + row0 + 4 * kq) = o;
-            st_x(xrsrc, xout, (unsigned)wg * chunk_stride, o, sync_mode);
-        }
-        stamp(j, 4);
-        if (kw == 0 && j + 1 < Tchain) {
-            // only this wave has stored: drain them, then one lane publishes the chain's step flag
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) {
-                if (sync_mode == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __hip_atomic_store(flags + wg * REC_FLAG_STRIDE, (unsigned)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        stamp(j, 5);
-    }
-}
-
+#include "recurrent_experiments_q8.inc"
 #endif  // SCTC_REC_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------
@@ -1699,150 +1405,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_s_kernel(RecArgs p)
 }
 
 #ifdef SCTC_REC_EXPERIMENTS    // superseded at 6..16 utterances by the single-chain flag kernel (round 5); SCTC_REC_VARIANT=42
-// ---------------------------------------------------------------------------------------
-// Mid-batch variant (6..16 utterances): the one-hop sentinel exchange of the small-batch kernel
-// with the matrix cores of the big ones.  A workgroup owns 16 output units; its 16 x H weight
-// slab lives in REGISTERS as MFMA A fragments (4 waves = 4 K quarters), because the LDS is
-// needed for the staged state: the polling waves (rows round-robin over the 4 waves) re-read
-// the previous state rows ([xbase[step] + utterance][H], write-through, sentinel-validated,
-// L2-bypassing) into LDS, from where every wave takes its B fragments as 16-byte reads.
-// NCQ = ceil(H/16/4) chunks per wave.
-template <int NCQ>
-__global__ __launch_bounds__(256, 1) void brnn_recurrent_m_kernel(RecArgs p)
-{
-    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = blockIdx.x & 1, wg = blockIdx.x >> 1;
-    const int Hp = p.Hp, nch = Hp >> 4;
-    const int row0 = wg * 16;
-    const int uj = lane & 15, kq = lane >> 4;
-    const int base = nch >> 2, rem = nch & 3;
-    const int cnt = base + (wave < rem ? 1 : 0);
-    const int c_beg = wave * base + min(wave, rem);
-    const int xld = Hp + 4;                                  // LDS row stride (floats): conflict-free b128 reads
-    float* xs = reinterpret_cast<float*>(lds4);              // [16][xld]
-    float4* red = lds4 + (size_t)(16 * xld) / 4;             // [3][64]
-
-    // ---- stationary weights as A fragments: wf[u] = { Wop[row0 + uj][16c + 4kq + q] }_q
-    float4 wf[NCQ];
-    {
-        const float* W = p.W[g];
-#pragma unroll
-        for (int u = 0; u < NCQ; ++u) {
-            const int c = c_beg + min(u, cnt - 1);
-            float4 v;
-            if (!p.transpose) {
-                v = *reinterpret_cast<const float4*>(W + (int64_t)(row0 + uj) * p.ldw + 16 * c + 4 * kq);
-            } else {
-                const float* col = W + (int64_t)(16 * c + 4 * kq) * p.ldw + row0 + uj;
-                v.x = col[0];
-                v.y = col[p.ldw];
-                v.z = col[2 * p.ldw];
-                v.w = col[3 * p.ldw];
-            }
-            wf[u] = v;
-        }
-    }
-    const bool desc = p.descending[g] != 0;
-    const float* pre = p.pre[g];
-    const float* act = p.act[g];
-    float* out = p.out[g];
-    const int64_t ld = p.ld;
-    const float hi = p.max_act > 0.f ? p.max_act : INFINITY;
-    unsigned* err = p.counters + 2;
-    float* xg = p.xbuf + (size_t)g * p.n_xrows * Hp;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        xg, 0, (int)((size_t)p.n_xrows * Hp * sizeof(float)), 0x00020000);
-    const int uT = uj < p.B ? p.T_b[uj] : 0;                 // lane's utterance (sorted, longest first)
-    const int n4 = Hp >> 2;
-    constexpr int NQ = (NCQ * 4 + 15) / 16;                  // float4 loads per lane for one state row
-
-    int xb_next = p.xbase[0], xb_cur = 0;
-    for (int j = 0; j < p.Tmax; ++j) {
-        const int xb_prev = xb_cur;
-        xb_cur = xb_next;
-        xb_next = p.xbase[min(j + 1, p.Tmax - 1)];
-        const int nb = __builtin_amdgcn_readfirstlane(__popcll(__ballot(j < uT && kq == 0)));   // active prefix
-        const bool active = j < uT;
-        const int t = desc ? uT - 1 - j : j;
-        const int64_t orow = active ? (int64_t)p.rowbase[t] + p.b_off + uj : 0;
-        float4 pre4 = make_float4(0.f, 0.f, 0.f, 0.f), act4 = pre4;
-        if (wave == 0 && active) {
-            pre4 = *reinterpret_cast<const float4*>(pre + orow * ld + row0 + 4 * kq);
-            if (act) act4 = *reinterpret_cast<const float4*>(act + orow * ld + row0 + 4 * kq);
-        }
-        f32x4 acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = {0.f, 0.f, 0.f, 0.f};
-        if (j > 0) {
-            // ---- stage the previous state: rows round-robin over the waves, re-read until complete
-            // (one row in flight per wave: requesting all rows of a wave at once was measured 10 %
-            // SLOWER at 8 utterances x 2048 units -- an early poll then re-reads twice the bytes)
-            first_poll_delay(p.poll_delay);
-            for (int bb = wave; bb < nb; bb += 4) {
-                const unsigned rowoff = (unsigned)(xb_prev + bb) * (unsigned)Hp * 4u;
-                const unsigned long long t0 = wall_clock64();
-                unsigned spins = 0;
-                u32x4 v[NQ];
-                for (;;) {   // all loads of the row in flight at once, then validate
-#pragma unroll
-                    for (int c = 0; c < NQ; ++c) {
-                        const int item = min(c * 64 + lane, n4 - 1);
-                        v[c] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (unsigned)item * 16u, rowoff, 16 /* sc1 */);
-                    }
-                    bool ok = true;
-#pragma unroll
-                    for (int c = 0; c < NQ; ++c)
-                        ok = ok && v[c][0] != XSENT && v[c][1] != XSENT && v[c][2] != XSENT && v[c][3] != XSENT;
-                    if (__all(ok)) break;
-                    if ((++spins & 255u) == 0) {
-                        if (spin_expired(err, t0, lane)) break;
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < NQ; ++c) {
-                    const int item = c * 64 + lane;
-                    if (item < n4)
-                        *reinterpret_cast<u32x4*>(xs + (size_t)bb * xld + 4 * item) = v[c];
-                }
-            }
-            __syncthreads();
-            // ---- products: B fragment of chunk c = { x[uj][16c + 4kq + q] }_q from LDS
-            const float* xrow = xs + (size_t)uj * xld + 4 * kq;
-#pragma unroll
-            for (int u = 0; u < NCQ; ++u) {
-                if (u < NCQ - 1 || cnt == NCQ) {
-                    const float4 x = *reinterpret_cast<const float4*>(xrow + 16 * (c_beg + u));
-                    SCTC_MFMA4(acc, wf[u], x)
-                }
-            }
-            if (wave != 0) {
-                const f32x4 sres = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-                red[(wave - 1) * 64 + lane] = make_float4(sres[0], sres[1], sres[2], sres[3]);
-            }
-            __syncthreads();
-        }
-        if (wave == 0 && active) {
-            float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j > 0) {
-                const float4 r1 = red[lane], r2 = red[64 + lane], r3 = red[128 + lane];
-                const f32x4 q = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-                sv = make_float4((q[0] + r1.x) + (r2.x + r3.x), (q[1] + r1.y) + (r2.y + r3.y),
-                                 (q[2] + r1.z) + (r2.z + r3.z), (q[3] + r1.w) + (r2.w + r3.w));
-            }
-            const float4 o = step_result(pre4, sv, act4, act != nullptr, hi);
-            *reinterpret_cast<float4*>(out + orow * ld + row0 + 4 * kq) = o;
-            const u32x4 ou = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(ou, xrsrc, (unsigned)(row0 + 4 * kq) * 4u,
-                                                   (unsigned)(xb_cur + uj) * (unsigned)Hp * 4u, 16 /* sc1 */);
-        }
-        // the next step's staging overwrites the state rows in LDS: every wave must be done reading
-        __syncthreads();
-    }
-}
-
-
+#include "recurrent_experiments_m.inc"
 #endif  // SCTC_REC_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------
