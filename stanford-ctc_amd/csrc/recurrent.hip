@@ -1096,6 +1096,16 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
                 if constexpr (cu < NCQ)
                     x[bi % R][u][i] = ld_x(xrsrc, xs[i], (unsigned)(c_beg + min(cu, cnt - 1)) * chunk_stride);
             };
+            // K quarters: wave c keeps its own partial sum of result c, the others park theirs in LDS.  Result c is final
+            // behind group c of the LAST chunk: parked behind the next group's MFMAs, under the matrix pipe -- only the last
+            // result's sum is taken with the pipe idle.
+            auto park = [&](auto c_c) {
+                constexpr int c = decltype(c_c)::value;
+                float4* rp = red + (size_t)(En.parity * NC * 3) * 64 + lane;
+                const f32x4 s = (acc[c & 1][c >> 1][0] + acc[c & 1][c >> 1][1]) + (acc[c & 1][c >> 1][2] + acc[c & 1][c >> 1][3]);
+                if (wave == c) En.mine = s;
+                else rp[(c * 3 + (wave < c ? wave : wave - 1)) * 64] = make_float4(s[0], s[1], s[2], s[3]);
+            };
             static_for<WA>([&](auto G_c) { prefetch_a(G_c); });
             static_for<NBAT>([&](auto b_c) {
                 constexpr int b = decltype(b_c)::value;
@@ -1121,6 +1131,10 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
                     mfma_group(b_c, std::integral_constant<int, s / NC>(), std::integral_constant<int, s % NC>());
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (b == 0 && s == 0) { setup(); __builtin_amdgcn_sched_barrier(0); }
+                    if constexpr (b * XB + s / NC == NCQ - 1 && s % NC >= 1) {
+                        park(std::integral_constant<int, s % NC - 1>());
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if constexpr (s % NC == NC - 1) stamp_chunk(sub, j, 1 + b * XB + s / NC);
                     if constexpr (b == 0) {
                         if constexpr (s % NC == NC - 1 && s / NC < 5) stamp(sub, j, 1 + s / NC);
@@ -1160,14 +1174,7 @@ __global__ __launch_bounds__(256, 1) void brnn_recurrent_t_kernel(RecArgs p)
                 }
             });
             stamp(sub, j, 7);
-            // K quarters: wave c keeps its own partial sum of result c, the others park theirs in LDS
-            float4* rp = red + (size_t)(En.parity * NC * 3) * 64 + lane;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const f32x4 s = (acc[c & 1][c >> 1][0] + acc[c & 1][c >> 1][1]) + (acc[c & 1][c >> 1][2] + acc[c & 1][c >> 1][3]);
-                if (wave == c) En.mine = s;
-                else rp[(c * 3 + (wave < c ? wave : wave - 1)) * 64] = make_float4(s[0], s[1], s[2], s[3]);
-            }
+            park(std::integral_constant<int, NC - 1>());       // (the other results were parked between the last chunk's groups)
         } else {
             En.mine = {0.f, 0.f, 0.f, 0.f};
         }
