@@ -82,13 +82,35 @@ int ctc_make_plan(int B, int A, int blank, int dtype, const int32_t* T_b, const 
             plan->lp = 64 * K;
         }
         plan->store_bytes = (dtype == SCTC_F32 && !(sb && atoi(sb) == 64)) ? 4 : 8;
+        // Rows of 513..2048 states (round 6): the same schedule on W = 4 / 8 waves per direction (ctc_fusedw.hip), from
+        // SCTC_CTC_WIDE_MIN_B utterances on (default 12; rows of up to 1024 states, four waves: 16).  Below that the lattice
+        // + grad kernels are faster -- their gradient kernel spreads over the CUs the few recursion workgroups leave idle
+        // (cfg-5 shape, T = 8000 / U = 800, 8 utterances: 5.13 against 5.38 ms; 16: 5.72 against 5.45; 128: 15.5 against 6.0;
+        // T = 4000 / U = 511: 8: 1.99 against 2.15, 16: 2.15 / 2.16, 64: 3.06 against 2.25) -- at five times the traffic
+        // and ten times the workspace.
+        // SCTC_CTC_WIDE=0 keeps the lattice + grad kernels throughout, =1 takes the wide kernel whatever the batch and for
+        // shorter rows too (tests); SCTC_CTC_WAVES=8 forces eight waves.
+        const char* wz = getenv("SCTC_CTC_WIDE");
+        const char* wb = getenv("SCTC_CTC_WIDE_MIN_B");
+        const int wide = wz ? atoi(wz) : -1;
+        const bool fused_on = fz ? atoi(fz) != 0 : true;
+        const bool wide_auto = !plan->fused && B >= (wb ? atoi(wb) : (max_L > 1024 ? 12 : 16));
+        if (!plan->generic && !plan->lazy && A <= 256 && max_L <= 2048 && fused_on && wide != 0 && (wide == 1 || wide_auto)) {
+            const char* force = getenv("SCTC_CTC_WAVES");
+            W = (max_L > 1024 || (force && atoi(force) == 8)) ? 8 : 4;
+            K = max_L <= 64 * W * 2 ? 2 : 4;
+            plan->fused = 2;
+            plan->K = K;
+            plan->W = W;
+            plan->lp = 64 * W * K;
+        }
     }
     const size_t head = align256(sizeof(CtcUtt) * B) + align256(sizeof(int32_t) * (2 * n_labels + (int64_t)B * (A + 1)));
     if (plan->fused) {
         int64_t elems = 0;
         for (int b = 0; b < B; ++b) elems += K + (int64_t)T_b[b] * round_up(2 * U_b[b] + 1, K);
         plan->lat_elems = elems;
-        plan->bytes = head + align256((size_t)plan->store_bytes * elems);
+        plan->bytes = head + align256((size_t)plan->store_bytes * elems) + (plan->fused == 2 ? align256(ctc_fusedw_sync_bytes(B)) : 0);
         return SCTC_OK;
     }
     plan->lat_elems = frames * plan->lp;
@@ -127,8 +149,10 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
     double *d_ll = nullptr, *d_alpha = nullptr, *d_beta = nullptr, *d_scratch = nullptr;
     int32_t* d_skip2 = nullptr;
     char* d_store = nullptr;
+    uint32_t* d_sync = nullptr;
     if (plan.fused) {
         d_store = ar.take<char>((size_t)plan.store_bytes * plan.lat_elems);
+        if (plan.fused == 2) d_sync = ar.take<uint32_t>(ctc_fusedw_sync_bytes(plan.B) / sizeof(uint32_t));
     } else {
         d_ll = ar.take<double>(2 * plan.B);
         d_skip2 = ar.take<int32_t>(2 * plan.B);
@@ -218,7 +242,9 @@ static int run_ctc(const sctc_ctc_batch* bt, const CtcPlan& plan, const R* probs
                 fprintf(stderr, "sctc: SCTC_CTC_DIAG=%d is set: the fused CTC kernel skips parts of its schedule, costs and "
                                 "gradients are WRONG (diagnostic timing runs only; unset it)\n", fa.diag);
         }
-        SCTC_TRY(launch_ctc_fused<R>(fa, plan.B, plan.K, plan.store_bytes, stream));
+        fa.sync = d_sync;
+        if (plan.fused == 2) SCTC_TRY(launch_ctc_fusedw<R>(fa, plan.B, plan.K, plan.W, plan.store_bytes, stream));
+        else SCTC_TRY(launch_ctc_fused<R>(fa, plan.B, plan.K, plan.store_bytes, stream));
         if (!staged_pinned) SCTC_HIP_TRY(hipStreamSynchronize(stream));   // pageable staging must outlive the copies
         return SCTC_OK;
     }

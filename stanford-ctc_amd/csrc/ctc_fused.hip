@@ -55,43 +55,10 @@
 
 #include "common.h"
 #include "ctc_kernels.h"
+#include "ctc_store.h"
 #include "xlane.h"
 
 namespace sctc {
-
-namespace {
-
-template <typename ST>
-struct Store;
-template <>
-struct Store<double> {
-    static __device__ __forceinline__ double enc(double x) { return x; }
-    static __device__ __forceinline__ double dec(double s) { return s; }
-};
-template <>
-struct Store<uint32_t> {
-    static __device__ __forceinline__ uint32_t enc(double x)
-    {
-        return (uint32_t)(((uint64_t)__double_as_longlong(x) + (1ull << 29)) >> 30);
-    }
-    static __device__ __forceinline__ double dec(uint32_t s)
-    {
-        return __longlong_as_double((long long)((uint64_t)s << 30));
-    }
-};
-
-// K stored states as one memory block; the reader's block is K-element contiguous but only
-// element-aligned (it mirrors the writer's lane order), so the type promises no more than that
-template <typename ST, int K>
-struct __attribute__((packed, aligned(sizeof(ST)))) RowBlockU {
-    ST v[K];
-};
-template <typename ST, int K>
-struct __attribute__((aligned(sizeof(ST) * K))) RowBlockA {
-    ST v[K];
-};
-
-}  // namespace
 
 // The two-wave form on float32 probabilities with 32-bit rows, up to 4 states per lane, up to 64 symbols (the
 // saturating-batch form of BASELINE configs[0..2]) goes on a REGISTER DIET (round 6): SQ counters showed

@@ -74,9 +74,15 @@ struct CtcFusedArgs {
     int32_t* skip;   // [B]
     int32_t diag;    // SCTC_CTC_DIAG, timing experiments only (results are wrong): 1 no phase 1, 2 helper without
                      // finish, 4 helper without products, 8 recursion waves do not wait for the helper
+    uint32_t* sync;  // ctc_fusedw.hip only: ctc_fusedw_sync_bytes(B) of flag words (the launcher zeroes them)
 };
 template <typename RI>
 int launch_ctc_fused(const CtcFusedArgs<RI>& a, int B, int K, int store_bytes, hipStream_t stream);
+// ctc_fusedw.hip: the same schedule for rows of 513..2048 states -- one workgroup of W = 4 / 8 waves per (utterance,
+// direction), K = 2 / 4 states per lane; the store is laid out like the narrow kernel's
+template <typename RI>
+int launch_ctc_fusedw(const CtcFusedArgs<RI>& a, int B, int K, int W, int store_bytes, hipStream_t stream);
+size_t ctc_fusedw_sync_bytes(int B);
 
 // K states per lane and W waves per (utterance, pass) for rows of up to max_L states;
 // returns K (0 if 2U+1 > 2048: the generic kernels take over), *waves = W; the lattice row stride is 64*W*K
@@ -100,8 +106,9 @@ struct CtcPlan {
     int B = 0, A = 0, blank = 0, K = 0, W = 1, lp = 0, max_T = 0;   // lp = 64*W*K
     int lazy = 0;           // SCTC_CTC_LAZY=1: float32 probabilities rescale every 4th frame only
     int generic = 0;        // ctc_generic.hip: 2U+1 > 2048 or A > 256 (or SCTC_CTC_GENERIC=1); lp = round_up(2U+2, 64)
-    int fused = 0;          // ctc_fused_kernel (one wave per direction, rows of <= 512 states); lat_elems then counts
-                            // the elements of its ONE packed row store, store_bytes (4 / 8) each
+    int fused = 0;          // 1: ctc_fused_kernel (one wave per direction, rows of <= 512 states), 2: ctc_fusedw_kernel (W waves
+                            // per direction, rows of <= 2048 states); lat_elems then counts the elements of the ONE packed
+                            // row store, store_bytes (4 / 8) each
     int store_bytes = 8;
     int64_t frames = 0;
     int64_t lat_elems = 0;  // elements per lattice (alpha or beta)

@@ -2,6 +2,8 @@
 
   fused     ctc_fused.hip      both recursions + the gradient in one kernel, rows of <= 512 states (default there);
                                "fused2w" = the same without helper waves (SCTC_CTC_HELPER=0)
+  wide      ctc_fusedw.hip     round 6: the fused schedule on 4 / 8 waves per direction, rows of 513..2048 states (default
+                               there; SCTC_CTC_WIDE=1 forces it for every row, SCTC_CTC_WAVES=8 eight waves: "wide8")
   lattice   ctc_kernels.hip    ctc_lattice + ctc_grad, rows of <= 2048 states (SCTC_CTC_FUSED=0 forces it)
   generic   ctc_generic.hip    any label length, any alphabet (SCTC_CTC_GENERIC=1 forces it)
 
@@ -34,8 +36,14 @@ class path:
     ENV = {"fused": {}, "fused64": {"SCTC_CTC_STORE": "64"}, "fused2w": {"SCTC_CTC_HELPER": "0"},
            # round 6: the two-wave form on its register diet (three waves per SIMD; by default from 1537 utterances on)
            "fused2wd": {"SCTC_CTC_HELPER": "0", "SCTC_CTC_DIET_MIN_B": "1"},
+           # round 6: the meet-in-the-middle kernel for long rows (ctc_fusedw.hip: 4 / 8 waves per direction; by default for
+           # rows of 513..2048 states) forced for every row
+           "wide": {"SCTC_CTC_WIDE": "1"}, "wide8": {"SCTC_CTC_WIDE": "1", "SCTC_CTC_WAVES": "8"},
+           "wide64": {"SCTC_CTC_WIDE": "1", "SCTC_CTC_STORE": "64"},
+           "widemin1": {"SCTC_CTC_WIDE_MIN_B": "1"},      # the default dispatch (rows of 513..2048 states only) from one utterance on
            "lattice": {"SCTC_CTC_FUSED": "0"}, "generic": {"SCTC_CTC_GENERIC": "1"}}
-    VARS = ("SCTC_CTC_STORE", "SCTC_CTC_FUSED", "SCTC_CTC_GENERIC", "SCTC_CTC_HELPER", "SCTC_CTC_DIET_MIN_B")
+    VARS = ("SCTC_CTC_STORE", "SCTC_CTC_FUSED", "SCTC_CTC_GENERIC", "SCTC_CTC_HELPER", "SCTC_CTC_DIET_MIN_B", "SCTC_CTC_WIDE",
+            "SCTC_CTC_WAVES", "SCTC_CTC_WIDE_MIN_B")
 
     def __init__(self, name):
         self.env = self.ENV[name]
@@ -90,7 +98,7 @@ SHAPES = [  # (A, T, U): one and two states per lane pair, every T parity around
 ]
 
 
-@pytest.mark.parametrize("which", ["fused", "fused2w", "lattice", "generic"])
+@pytest.mark.parametrize("which", ["fused", "fused2w", "wide", "wide8", "lattice", "generic"])
 def test_paths_f64_vs_oracle(mods, which):
     cf, octc, _ = mods
     rs = np.random.RandomState(11)
@@ -105,7 +113,7 @@ def test_paths_f64_vs_oracle(mods, which):
     print("%s: worst float64 gradient error %.1e over %d cases" % (which, worst, len(SHAPES) * 6))
 
 
-@pytest.mark.parametrize("which", ["fused", "fused2w", "generic"])
+@pytest.mark.parametrize("which", ["fused", "fused2w", "wide", "wide8", "generic"])
 def test_paths_quirks(mods, golden, which):
     """the reference's skip / empty band / T = 1 behaviour on the round-5 paths (test_gpu_ctc.py holds the same
     for the default dispatch)"""
@@ -188,7 +196,7 @@ def test_fused_f32_row_store(mods):
         with np.errstate(all="ignore"):
             c_ref, g_ref, s_ref = octc.ctc_loss(np.asfortranarray(y.astype(np.float64)), seq)
         res = {}
-        for which in ("fused", "fused64", "fused2w", "fused2wd", "lattice"):
+        for which in ("fused", "fused64", "fused2w", "fused2wd", "wide", "wide8", "wide64", "lattice"):
             with path(which), np.errstate(all="ignore"):
                 cost, grads, skip = cf.ctc_loss_batch([y], [seq])
             assert not skip[0] and not s_ref
@@ -220,7 +228,7 @@ def test_fused_ragged_batch_and_long_lists(mods):
         for b in range(37):
             with np.errstate(all="ignore"):
                 refs.append(octc.ctc_loss(np.asfortranarray(probs[b].astype(np.float64)), seqs[b]))
-        for which in ("fused", "fused2w", "fused2wd"):
+        for which in ("fused", "fused2w", "fused2wd", "wide", "wide8"):
             with path(which), np.errstate(all="ignore"):
                 cost, grads, skip = cf.ctc_loss_batch(probs, seqs)
             for b in range(37):
@@ -235,6 +243,72 @@ def test_fused_ragged_batch_and_long_lists(mods):
                     assert abs(cost[b] - c_ref) <= 1e-11 * abs(c_ref), (which, A, b)
                 tol = 1e-9 if dt == np.float64 else 2e-7
                 assert np.abs(grads[b].astype(np.float64) - g_ref).max() < tol, (which, A, b, probs[b].shape, len(seqs[b]))
+
+
+def test_wide_rows_513_to_2048_states(mods):
+    """rows of 513..2048 lattice states (BASELINE configs[4]: U = 800 -> 1601) on the wide meet-in-the-middle kernel
+    (the default dispatch takes it from 12 utterances on: single utterances here with
+    SCTC_CTC_WIDE_MIN_B=1, the batches below as dispatched), against the oracle and against the lattice + grad kernels of rounds 1-5:
+    the 512 / 513, 1024 / 1025 and 2047 edges of its shapes (4 waves x 2 and x 4 states, 8 x 4), labels that occur far more often than the 32
+    list entries a lane keeps in registers (A = 3), wide alphabets, blank ids at either end, float64 and float32
+    probabilities (32-bit rows), T odd / even / short of the band; then ragged batches of more utterances than one
+    round of 8 block pairs, with a skipping utterance and an empty band among them"""
+    cf, octc, _ = mods
+    rs = np.random.RandomState(29)
+    shapes = [(33, 700, 256), (33, 1201, 300), (33, 1100, 511), (33, 1300, 512), (3, 1700, 800), (33, 1650, 800),
+              (70, 2100, 1023), (130, 900, 400), (200, 1000, 600), (33, 1100, 1023), (33, 1024, 1023), (5, 3001, 640)]
+    worst64 = worst32 = 0.0
+    for A, T, U in shapes:
+        for blank in (0, A - 1):
+            y, seq = _case(rs, A, T, U, blank=blank, with_blank_labels=(U % 2 == 1))
+            with path("widemin1"):
+                worst64 = max(worst64, _check_f64(cf, octc, y, seq, blank, ("wide-auto", A, T, U, blank)))
+            y32 = np.asfortranarray(y.astype(np.float32))
+            with np.errstate(all="ignore"):
+                c_ref, g_ref, s_ref = octc.ctc_loss(np.asfortranarray(y32.astype(np.float64)), seq, blank)
+                with path("widemin1"):
+                    cost, grads, skip = cf.ctc_loss_batch([y32], [seq], blank)
+                with path("lattice"):
+                    cost_l, grads_l, skip_l = cf.ctc_loss_batch([y32], [seq], blank)
+            assert bool(skip[0]) == bool(s_ref) == bool(skip_l[0]), (A, T, U, blank)
+            if s_ref:       # (33, 1024, 1023): repeated labels need more frames than there are -- the band sum runs dry
+                assert not grads[0].any() and cost[0] == pytest.approx(c_ref, rel=1e-11)
+                continue
+            assert abs(cost[0] - c_ref) <= 1e-11 * abs(c_ref), (A, T, U, blank)
+            err = np.abs(grads[0].astype(np.float64) - g_ref).max()
+            worst32 = max(worst32, err)
+            assert err < 2e-7, (A, T, U, blank, err)
+            assert np.abs(grads[0].astype(np.float64) - grads_l[0]).max() < 2.5e-7
+    print("wide rows: worst |grad - oracle| float64 %.1e, float32 (32-bit rows) %.1e" % (worst64, worst32))
+    for dt, tol in ((np.float64, 1e-9), (np.float32, 2e-7)):
+        probs, seqs = [], []
+        for b in range(21):
+            U = int(rs.randint(257, 1024))
+            T = int(rs.randint(U, 2 * U + 50))
+            if b == 6:
+                T = U - 3                 # empty band: cost +inf, grad = probabilities
+            y, seq = _case(rs, 20, T, U, all_same=(b == 9))
+            if b == 13:
+                y[:, T // 2 + 5] = 0.0    # a zero band sum in phase 1 of both directions: skip, every row taken back
+            if b == 17:
+                y[:, 3] = 0.0             # ... and in phase 0 of alpha
+            probs.append(np.asfortranarray(y.astype(dt)))
+            seqs.append(seq)
+        with np.errstate(all="ignore"):
+            refs = [octc.ctc_loss(np.asfortranarray(probs[b].astype(np.float64)), seqs[b]) for b in range(21)]
+            cost, grads, skip = cf.ctc_loss_batch(probs, seqs)
+        for b in range(21):
+            c_ref, g_ref, s_ref = refs[b]
+            assert bool(skip[b]) == bool(s_ref), (dt, b)
+            if s_ref:
+                assert not grads[b].any(), (dt, b)
+                continue
+            if np.isinf(c_ref):
+                assert np.isinf(cost[b]) and cost[b] > 0
+            else:
+                assert abs(cost[b] - c_ref) <= 1e-11 * abs(c_ref), (dt, b)
+            assert np.abs(grads[b].astype(np.float64) - g_ref).max() < tol, (dt, b, probs[b].shape, len(seqs[b]))
+        assert skip[13] and skip[17] and np.isinf(cost[6])
 
 
 def test_long_label_rows_and_wide_alphabets(mods):
@@ -338,7 +412,43 @@ def test_long_label_row_through_the_network_and_the_trainer_check(mods):
     assert L.sctc_brnn_set_ctc_workspace(netf._h, None, 0) == -1     # a forward-only model has no CTC
 
 
-@pytest.mark.parametrize("which", ["fused", "fused2w", "lattice", "generic"])
+def test_wide_rows_through_the_network(mods):
+    """NNet.costAndGradBatch on a minibatch of 17 utterances with label rows of 601..1201 lattice states: the engine's CTC
+    call takes the wide fused kernel (12 utterances or more, 16 for rows of up to 1024 states; packed-minibatch row layout, float32 probabilities, 32-bit
+    rows) -- costs and every gradient against the float64 oracle, and against the same minibatch on the lattice + grad
+    kernels (SCTC_CTC_WIDE=0)"""
+    cf, octc, torch = mods
+    from nnets import brnnet
+    from oracle import brnn as obrnn
+    D, A, H, NL, TL, B = 8, 20, 32, 2, 1, 17
+    rs = np.random.RandomState(12)
+    Us = [int(rs.randint(300, 601)) for _ in range(B)]
+    Ts = [int(u + rs.randint(60, 400)) for u in Us]
+    datas = [rs.randn(D, t) for t in Ts]
+    labs = [rs.randint(1, A, size=u).astype(np.int32) for u in Us]
+    np.random.seed(3)
+    net = brnnet.NNet(D, A, H, NL, max(Ts), temporalLayer=TL, maxUtts=B)
+    net.initParams()
+    np.random.seed(3)
+    params = obrnn.init_params(D, A, H, NL, TL)
+    with np.errstate(all="ignore"):
+        cr, gr, sr, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+    res = {}
+    for which in ("fused", "lattice"):           # "fused" = default switches: the wide kernel at 17 utterances
+        with path(which):
+            costs, _, skips = net.costAndGradBatch(datas, labs)
+        assert not skips.any() and not sr.any()
+        np.testing.assert_allclose(costs, cr, rtol=1e-4)
+        for (dw, db), gw in zip(net.grad[:NL + 1], gr["W"]):
+            assert np.linalg.norm(dw.copy_to_host() - gw) <= 2e-4 * np.linalg.norm(gw) + 1e-7, which
+        res[which] = (costs.copy(), net.grad.flat.clone())
+    assert np.abs(res["fused"][0] - res["lattice"][0]).max() <= 1e-9 * np.abs(cr).max()
+    d = float((res["fused"][1] - res["lattice"][1]).double().norm() / res["lattice"][1].double().norm())
+    assert d < 1e-5, d
+    assert d > 0, "both runs took the same kernels?"
+
+
+@pytest.mark.parametrize("which", ["fused", "fused2w", "wide", "lattice", "generic"])
 def test_tiny_cost_is_the_log_of_the_band_sum_itself(mods, which):
     """one frame whose blank + label probabilities sum to 1 - 1e-8: the cost is 1e-8 and every path must return the
     logarithm of that very sum (rounds 1-4 took the logarithm of the applied reciprocal: 2e-8 relative error, found
