@@ -176,7 +176,8 @@ void ctc_fused_kernel(CtcFusedArgs<RI> p)
 #pragma unroll
     for (int j = 0; j < K; ++j) inrow[j] = K * gl + j < L;
     const bool store_lane = K * gl < stride;
-    const bool orow_lane = K * gl < L;
+    const int other_off = max(L - K * (gl + 1), -K);     // my block of the other direction's (mirrored) row
+    ST* const pad = reinterpret_cast<ST*>(p.store) + u.lat_off - K;   // K elements in front of the utterance's rows: the dump
 
     // ---- gradient side: lane k (+64q) owns label k's list of label positions, in MY direction's order
     int lidx[NA][NI2];
@@ -223,18 +224,27 @@ void ctc_fused_kernel(CtcFusedArgs<RI> p)
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
     };
+    // NO load or store of the frame loops sits under a branch, not even a lane mask (round 6): behind control flow the
+    // compiler no longer knows how many memory operations are in flight and every later wait becomes s_waitcnt vmcnt(0)
+    // -- a block's prefetch then waited for the rows (phase 0) or gradient rows (phase 1) stored behind the block before,
+    // an HBM write round trip per block of frames (found in ctc_fusedw.hip, where it cost 1.3 us per block).  Columns and
+    // rows are clamped and masked by a select; lanes / frames with nothing to store write to the pad in front of the
+    // utterance's rows, which nobody reads unmasked.
     auto load_row = [&](int64_t row, RI (&dst)[NA]) {
         const RI* yr = probs + row * ld;
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int k = lane + 64 * q;
-            dst[q] = k < A ? yr[k] : (RI)0;
+            const RI v = yr[min(k, A - 1)];
+            dst[q] = k < A ? v : (RI)0;
         }
     };
+    const int32_t* const rb_tab = p.rowbase ? p.rowbase : reinterpret_cast<const int32_t*>(p.utts);
     auto block_rows = [&](int tau0) -> int {
         const int tau = min(tau0 + lane, T - 1);
         const int t = dir ? T - 1 - tau : tau;
-        return (p.rowbase ? p.rowbase[t] : t);
+        const int v = rb_tab[p.rowbase ? t : 0];
+        return p.rowbase ? v : t;
     };
     auto gather = [&](const RI (&y)[NA], int k) -> R {
         RI out = lane_gather(y[0], k & 63);
@@ -275,12 +285,8 @@ void ctc_fused_kernel(CtcFusedArgs<RI> p)
     // the other direction's row of MY frame tau: its own time index is T-1-tau, its state order mine mirrored
     auto load_other = [&](int tau, BlkU& dst) {
         const int taup = T - 1 - min(tau, T - 1);
-        if (orow_lane) {
-            dst = *reinterpret_cast<const BlkU*>(other + (int64_t)taup * stride + (L - K * (gl + 1)));
-        } else {
-#pragma unroll
-            for (int j = 0; j < K; ++j) dst.v[j] = (ST)0;
-        }
+        // (a lane beyond the row reads the K elements in front of it; products masks them)
+        dst = *reinterpret_cast<const BlkU*>(other + (int64_t)taup * stride + other_off);
     };
     auto recip = [&](R c) -> R {   // ctc_lattice_kernel: hardware estimate + two Newton-Raphson steps (<= 1 ulp)
         R x = __builtin_amdgcn_rcp(c);
@@ -517,11 +523,11 @@ void ctc_fused_kernel(CtcFusedArgs<RI> p)
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int k = lane + 64 * q;
-            if (k < A) {
 #pragma unroll
-                for (int i = 0; i < NF; ++i)
-                    if (tb + i < t_end)
-                        grad[((int64_t)__builtin_amdgcn_readlane(rows, i) + u.row0) * ld + k] = out[i][q];
+            for (int i = 0; i < NF; ++i) {
+                RI* dst = (k < A && tb + i < t_end) ? grad + ((int64_t)__builtin_amdgcn_readlane(rows, i) + u.row0) * ld + k
+                                                    : reinterpret_cast<RI*>(pad);
+                *dst = out[i][q];
             }
         }
         // the next block's products overwrite the slots: LDS executes a wave's accesses in order, the
@@ -598,11 +604,10 @@ void ctc_fused_kernel(CtcFusedArgs<RI> p)
                 if constexpr (!HELP)
                     finish_block(std::integral_constant<int, PF>(), &red_s[dir][0][0], [] {}, tb, t_end, ycur, rb_cur, zl, eb);
             } else {
-                if (store_lane) {
 #pragma unroll
-                    for (int i = 0; i < PF; ++i)
-                        if (tb + i < t_end)
-                            *reinterpret_cast<BlkA*>(mine + (int64_t)(tb + i) * stride + K * gl) = enc[i];
+                for (int i = 0; i < PF; ++i) {
+                    ST* dst = (store_lane && tb + i < t_end) ? mine + (int64_t)(tb + i) * stride + K * gl : pad;
+                    *reinterpret_cast<BlkA*>(dst) = enc[i];
                 }
             }
             if (first_bad != NO_BAD) skip = 1;
