@@ -20,9 +20,13 @@ import torch  # noqa: E402
 import ctc_fast  # noqa: E402
 
 SHAPES = {"cfg3": (32, 1000, 100, 33), "sat": (4096, 1000, 100, 33), "cfg2": (256, 300, 60, 62),
-          "cfg5": (8, 8000, 800, 33), "sat1k": (1024, 1000, 100, 33), "cfg4": (32, 2000, 200, 33), "sat4": (2048, 2000, 200, 33)}
+          "cfg5": (8, 8000, 800, 33), "sat1k": (1024, 1000, 100, 33), "cfg4": (32, 2000, 200, 33), "sat4": (2048, 2000, 200, 33),
+          # rows of 1601 states (ctc_fusedw.hip from 12 utterances on): cfg-5's minibatch and larger ones
+          "cfg5x32": (32, 8000, 800, 33), "cfg5x128": (128, 8000, 800, 33)}
 PATHS = {"fused": {}, "fused64": {"SCTC_CTC_STORE": "64"}, "fused2w": {"SCTC_CTC_HELPER": "0"},
-         "lattice": {"SCTC_CTC_FUSED": "0"}}
+         "lattice": {"SCTC_CTC_FUSED": "0"},
+         # the wide fused kernel whatever the batch size (rows of 513..2048 states only)
+         "wide": {"SCTC_CTC_WIDE_MIN_B": "1"}}
 
 
 def main():
@@ -41,7 +45,7 @@ def main():
         algo = B * (2 * 4 * A * T + 4 * U + 8)
         ref = None
         for pname in args.paths.split(","):
-            for k in ("SCTC_CTC_STORE", "SCTC_CTC_FUSED", "SCTC_CTC_HELPER"):
+            for k in ("SCTC_CTC_STORE", "SCTC_CTC_FUSED", "SCTC_CTC_HELPER", "SCTC_CTC_WIDE_MIN_B"):
                 os.environ.pop(k, None)
             os.environ.update(PATHS[pname])
             cost, grad, skip = ctc_fast.ctc_loss_batch(probs, seqs, lengths=[T] * B)     # warm-up (allocator, code objects)
