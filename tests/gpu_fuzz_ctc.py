@@ -2,7 +2,8 @@
 on the GPU; tests/test_gpu_fuzz.py runs a 20-case subset with a fixed seed in the suite): random alphabet, ragged
 batches, repeats, labels equal to the blank, T < U (empty band), infeasible repeats and
 zero-probability labels (skip), peaked and flat distributions, float32 and float64 I/O,
-one- and four-wave lattices."""
+one- and four-wave lattices; round 6: rows of up to 2001 states in batches of up to 20 (the wide fused kernel from 12 / 16
+utterances on; `SCTC_CTC_WIDE=1 python tests/gpu_fuzz_ctc.py ...` soaks it on every shape)."""
 import os
 import sys
 
@@ -22,14 +23,18 @@ def run(n_cases=60, seed=0):
     n_skip = n_inf = 0
     for case in range(n_cases):
         A = int(rs.choice([3, 5, 28, 33, 62, 100, 200]))
-        B = int(rs.choice([1, 2, 5, 9, 32]))
+        B = int(rs.choice([1, 2, 5, 9, 13, 20, 32]))
         blank = int(rs.choice([0, 0, 0, A - 1, A // 2]))
         long_rows = rs.rand() < 0.25          # > 256 lattice states: the four-wave kernel
+        very_long = B <= 20 and rs.rand() < 0.2   # up to 2001 states: four / eight waves, the wide fused kernel from 12 / 16 utterances on
         peaked = rs.rand() < 0.5
         f64 = rs.rand() < 0.4
         probs, seqs = [], []
         for b in range(B):
-            if long_rows:
+            if very_long:
+                U = int(rs.randint(200, 1001))
+                T = int(rs.randint(U, 2 * U + 40))
+            elif long_rows:
                 U = int(rs.randint(130, 420))
                 T = int(rs.randint(U, 3 * U))
             else:
@@ -66,7 +71,7 @@ def run(n_cases=60, seed=0):
             tol_c, tol_g = (1e-10, 1e-8) if f64 else (1e-5, 2e-5)
             assert dc < tol_c and dg < tol_g, (case, b, A, probs[b].shape, len(seqs[b]), f64, dc, dg)
             worst_c, worst_g = max(worst_c, dc if f64 else 0.0), max(worst_g, dg if f64 else 0.0)
-        print("case %2d A=%3d B=%2d blank=%3d long=%d peaked=%d f64=%d ok" % (case, A, B, blank, long_rows, peaked, f64), flush=True)
+        print("case %2d A=%3d B=%2d blank=%3d long=%d peaked=%d f64=%d ok" % (case, A, B, blank, 2 if very_long else long_rows, peaked, f64), flush=True)
     print("all %d cases agree (%d skipped utterances, %d empty bands; float64 worst: cost %.1e grad %.1e)"
           % (n_cases, n_skip, n_inf, worst_c, worst_g))
 
