@@ -543,6 +543,7 @@ def main():
             gemm_frac_with_separate_sums(out, torch, cfg, labels, feats)
             f32_split_bf16x3(out, torch, cfg, labels, feats, net)
             ctc_saturation(out, torch, A, T, U)
+            ctc_long_rows(out, torch)
             del net, feats, dev_bufs
             torch.cuda.empty_cache()
             small_configs(out, torch)
@@ -756,7 +757,7 @@ def ctc_saturation(out, torch, A, T, U):
     if files:
         pm = json.load(open(files[-1]))
         h = hashlib.sha256()
-        for f in ("ctc_fused.hip", "ctc_kernels.h", "xlane.h", "common.h"):
+        for f in ("ctc_fused.hip", "ctc_store.h", "ctc_kernels.h", "xlane.h", "common.h"):
             h.update(open(os.path.join(ROOT, "stanford-ctc_amd", "csrc", f), "rb").read())
         sat = out["roofline_ctc"]["saturating_batch"]
         if pm.get("source_hash_ctc") != h.hexdigest()[:16]:
@@ -776,11 +777,60 @@ def ctc_saturation(out, torch, A, T, U):
                                    "shader_clock_GHz_while_profiled": k.get("shader_clock_GHz_while_profiled"),
                                    "source": os.path.basename(files[-1])}
                 sat["bound_note"] = ("SQ counters of ctc_fused_kernel at this batch (rocprofv3 --pmc, %s): the device's SIMDs execute a VALU "
-                                     "instruction in valu_busy of their cycles with two recursion waves per SIMD (194 registers); a wave has one "
+                                     "instruction in valu_busy of their cycles with three recursion waves per SIMD (168 registers; round 5: two, 194, "
+                                     "0.64); a wave has one "
                                      "executing in wave_valu_busy of its resident time, waits at s_waitcnt / barriers in wave_parked and on "
                                      "dependencies in wave_issue_stalled: neither the float64 pipe's issue slots (>= 0.8) nor latency alone (< 0.6) -- "
                                      "HBM is not the bound at any batch" % os.path.basename(files[-1]))
                 out["roofline_ctc"]["bound"] = "issue + latency (float64 recursion; see saturating_batch.bound / valu_busy); HBM fraction reported for the record"
+
+
+def ctc_long_rows(out, torch):
+    """roofline_ctc.long_rows: label rows of 1601 lattice states (the cfg-5 shape, T = 8000 / U = 800) at 32 utterances --
+    the wide fused kernel (ctc_fusedw.hip, the default from 12 utterances on) beside the lattice + grad kernels it
+    replaces there (SCTC_CTC_WIDE=0), events around the Python entry on device-resident float32 probabilities"""
+    import ctc_fast
+    A, T, U, B = 33, 8000, 800, 32
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    probs = torch.softmax(torch.randn(B * T, A, device="cuda", generator=g), dim=1)
+    rs = np.random.RandomState(7)
+    seqs = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
+    ms, cost = {}, {}
+    old = os.environ.get("SCTC_CTC_WIDE")
+    try:
+        for name, env in (("wide", None), ("lattice_grad", "0")):
+            os.environ.pop("SCTC_CTC_WIDE", None)
+            if env is not None:
+                os.environ["SCTC_CTC_WIDE"] = env
+            c, _, _ = ctc_fast.ctc_loss_batch(probs, seqs, lengths=[T] * B)
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                c, _, _ = ctc_fast.ctc_loss_batch(probs, seqs, lengths=[T] * B)
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            ms[name] = best
+            cost[name] = np.asarray(c.cpu() if hasattr(c, "cpu") else c, dtype=np.float64)
+            torch.cuda.empty_cache()
+    finally:
+        os.environ.pop("SCTC_CTC_WIDE", None)
+        if old is not None:
+            os.environ["SCTC_CTC_WIDE"] = old
+    byts = B * (2 * 4 * A * T + 4 * U + 8)
+    out["roofline_ctc"]["long_rows"] = {
+        "shape": "T=8000 U=800 (1601 lattice states), %d symbols" % A, "utterances": B,
+        "ms": ms["wide"], "achieved": byts / (ms["wide"] * 1e-3) / 1e9, "unit": "GB/s",
+        "ms_lattice_grad": ms["lattice_grad"], "achieved_lattice_grad": byts / (ms["lattice_grad"] * 1e-3) / 1e9,
+        "max_cost_rel_distance": float(np.max(np.abs(cost["wide"] - cost["lattice_grad"]) / np.abs(cost["lattice_grad"]))),
+        "note": "ctc_fusedw_kernel (meet in the middle on 8 waves per direction, one packed 32-bit row store; default from 12 "
+                "utterances on) against ctc_lattice_kernel + ctc_grad_kernel (two float64 lattices; SCTC_CTC_WIDE=0) on the same "
+                "batch; HBM traffic of the two: profiles/r06_ctc_traffic_cfg5.txt (37x against 175x algorithmic at 8 utterances)"}
+    del probs
+    torch.cuda.empty_cache()
 
 
 def f32_split_bf16x3(out, torch, cfg, labels, feats, net32):

@@ -8,6 +8,8 @@ print("value %.0f %s  ms %.3f  frac %.4f  traffic %s" % (d["value"], d["unit"], 
 print("phases", {k: round(v, 3) for k, v in d.get("phase_ms", {}).items()})
 rc = d.get("roofline_ctc", {})
 print("ctc", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in rc.items() if k in ("achieved", "frac", "ms", "traffic", "traffic_ratio", "algorithmic_bytes")})
+if "long_rows" in rc:
+    print("ctc long rows", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in rc["long_rows"].items() if k != "note"})
 if "saturating_batch" in rc:
     print("ctc saturating", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in rc["saturating_batch"].items() if k != "note"})
 if "hbm_resident" in d:

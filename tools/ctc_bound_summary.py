@@ -39,7 +39,7 @@ for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_trace.csv"), recur
 import hashlib
 csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stanford-ctc_amd", "csrc")
 h = hashlib.sha256()
-for f in ("ctc_fused.hip", "ctc_kernels.h", "xlane.h", "common.h"):
+for f in ("ctc_fused.hip", "ctc_store.h", "ctc_kernels.h", "xlane.h", "common.h"):
     h.update(open(os.path.join(csrc, f), "rb").read())
 out = {"shape": shape, "source_hash_ctc": h.hexdigest()[:16], "kernels": {}}
 for name, cs in vals.items():
