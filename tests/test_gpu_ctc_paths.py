@@ -412,6 +412,37 @@ def test_long_label_row_through_the_network_and_the_trainer_check(mods):
     assert L.sctc_brnn_set_ctc_workspace(netf._h, None, 0) == -1     # a forward-only model has no CTC
 
 
+def test_cfg5_rows_at_12_utterances_through_the_network(mods):
+    """BASELINE configs[4]'s utterance shape (T = 8000, U = 800: 1601 lattice states, 33 symbols) at the smallest
+    minibatch the dispatch gives to the wide fused kernel (12), through NNet.costAndGradBatch on a small network:
+    costs and gradients against the float64 oracle and against the lattice + grad kernels (SCTC_CTC_WIDE=0)"""
+    cf, octc, torch = mods
+    from nnets import brnnet
+    from oracle import brnn as obrnn
+    D, A, H, NL, TL, B, T, U = 6, 33, 16, 2, 1, 12, 8000, 800
+    rs = np.random.RandomState(21)
+    datas = [rs.randn(D, T) for _ in range(B)]
+    labs = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
+    np.random.seed(5)
+    net = brnnet.NNet(D, A, H, NL, T, temporalLayer=TL, maxUtts=B)
+    net.initParams()
+    np.random.seed(5)
+    params = obrnn.init_params(D, A, H, NL, TL)
+    with np.errstate(all="ignore"):
+        cr, gr, sr, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
+    res = {}
+    for which in ("fused", "lattice"):
+        with path(which):
+            costs, _, skips = net.costAndGradBatch(datas, labs)
+        assert not skips.any() and not sr.any()
+        np.testing.assert_allclose(costs, cr, rtol=1e-4)
+        for (dw, db), gw in zip(net.grad[:NL + 1], gr["W"]):
+            assert np.linalg.norm(dw.copy_to_host() - gw) <= 3e-4 * np.linalg.norm(gw) + 1e-7, which
+        res[which] = (costs.copy(), net.grad.flat.clone())
+    d = float((res["fused"][1] - res["lattice"][1]).double().norm() / res["lattice"][1].double().norm())
+    assert 0 < d < 1e-5, d
+
+
 def test_wide_rows_through_the_network(mods):
     """NNet.costAndGradBatch on a minibatch of 17 utterances with label rows of 601..1201 lattice states: the engine's CTC
     call takes the wide fused kernel (12 utterances or more, 16 for rows of up to 1024 states; packed-minibatch row layout, float32 probabilities, 32-bit
