@@ -412,6 +412,37 @@ def test_long_label_row_through_the_network_and_the_trainer_check(mods):
     assert L.sctc_brnn_set_ctc_workspace(netf._h, None, 0) == -1     # a forward-only model has no CTC
 
 
+def test_32bit_rows_where_the_overlap_is_denormal(mods):
+    """The cfg-5 utterance shape (T = 8000, U = 800) on flat random probabilities is where the reference's own per-frame
+    scaling runs out of float64: around t = U and t = T - U the overlap sum_s alpha_t[s] beta_t[s] of the two normalised rows
+    is 1e-317 (a denormal with seven significant bits) or underflows to 0 (the reference then returns grad = y for the
+    frame).  What the reference computes there is rounding noise of ITS operation order; a row store that rounds one factor
+    to 22 mantissa bits (the 32-bit rows of the two fused kernels) reproduces it to 2e-6, everything else to 2e-7 -- pinned
+    here frame by frame against a NumPy restatement of the lattices; float64 rows (SCTC_CTC_STORE=64) and the lattice + grad
+    kernels reproduce the noise too."""
+    cf, octc, _ = mods
+    from tests import test_ctc_store_model as model
+    T, U, A = 8000, 800, 33
+    y, seq = model.inputs(T, U, A, 12)          # (seed 12: the model's worst of 20 seeds, 8e-7)
+    al, be, lab = model.both(y, seq)
+    overlap = (al * be).sum(axis=1)
+    assert overlap.min() == 0.0 and (overlap < 1e-300).sum() > 20        # the shape does what the docstring says
+    with np.errstate(all="ignore"):
+        c_ref, g_ref, s_ref = octc.ctc_loss(y, seq)
+    y32 = np.asfortranarray(y.astype(np.float32))                        # (exact: the model's inputs are float32 values)
+    assert not s_ref and (y32.astype(np.float64) == y).all()
+    sound = overlap > 1e-290
+    for which, bound_noise in (("widemin1", 5e-6), ("wide64", 2e-7), ("lattice", 2e-7)):
+        with path(which), np.errstate(all="ignore"):
+            cost, grads, skip = cf.ctc_loss_batch([y32], [seq])
+        assert not skip[0] and abs(cost[0] - c_ref) <= 1e-11 * abs(c_ref)
+        err = np.abs(grads[0].astype(np.float64) - g_ref).max(axis=0)     # per frame
+        assert err[sound].max() < 2e-7, (which, err[sound].max())
+        assert err[~sound].max() < bound_noise, (which, err[~sound].max())
+        print("%s: worst |grad - oracle| %.1e where the overlap is a normal number (%d frames), %.1e where it is not (%d)"
+              % (which, err[sound].max(), sound.sum(), err[~sound].max(), (~sound).sum()))
+
+
 def test_cfg5_rows_at_12_utterances_through_the_network(mods):
     """BASELINE configs[4]'s utterance shape (T = 8000, U = 800: 1601 lattice states, 33 symbols) at the smallest
     minibatch the dispatch gives to the wide fused kernel (12), through NNet.costAndGradBatch on a small network:
