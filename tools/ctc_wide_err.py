@@ -1,8 +1,18 @@
-import os, sys
+#!/usr/bin/env python3
+"""Per utterance: worst |grad - oracle| of the wide fused CTC kernel with 32-bit rows, with float64 rows and of the lattice + grad
+kernels at the cfg-5 shape (T = 8000, U = 800), and where (frame, symbol) it occurs -- the frames around t = U and t = T - U,
+where the reference's own alpha-beta overlap is a float64 denormal.  usage: tools/ctc_wide_err.py [B]"""
+import os
+import sys
+
 import numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/stanford-ctc_amd")
-import torch, ctc_fast
-from oracle import ctc as octc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "stanford-ctc_amd"))
+import torch  # noqa: E402
+import ctc_fast  # noqa: E402
+from oracle import ctc as octc  # noqa: E402
 A, T, U, B = 33, 8000, 800, int(sys.argv[1]) if len(sys.argv) > 1 else 32
 g = torch.Generator(device="cuda"); g.manual_seed(7)
 probs = torch.softmax(torch.randn(B * T, A, device="cuda", generator=g), dim=1)
