@@ -28,6 +28,8 @@
 // sequence, which sat on every frame's critical path), and the applied factors are not
 // tracked in registers but stored into the one lattice column no state ever occupies
 // (2U+1 is odd, the row stride even) and summed up after the last frame.
+#include <type_traits>
+
 #include "common.h"
 #include "ctc_kernels.h"
 #include "xlane.h"
@@ -561,7 +563,10 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(CtcLatticeArgs<RI> 
 
 // ---------------------------------------------------------------- ctc_grad
 
-template <typename RI>
+// NB: 64-state slices of the two lattice rows fetched per trip (launcher: by the row stride; its own instantiation per
+// value -- sixteen slices of two float64 lattices are 128 registers, which the short-row shapes, eight blocks to a CU, do
+// not have)
+template <typename RI, int NB>
 __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<RI> p)
 {
     using R = double;
@@ -636,20 +641,23 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<RI> p)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    R zpart = (R)0;
-    constexpr int NB = 8;
+    // Round 6: written for latency.  A frame used to cost its wave ~20 us at L = 1601 -- four dependent trips of
+    // eight lattice loads each (a memory round trip per trip) and then the blank lane's chain of (L + 1) / 2 dependent
+    // additions while 63 lanes watched (0.63 ms per cfg-5 step of 8 utterances, 1.3 TB/s).  Now sixteen slices per trip
+    // (two trips at most), loads unconditional (clamped, masked by a select: a load under a lane mask is waited for at
+    // once), and the blank sum in parallel: lane l holds the states l, l + 64, ... -- an even lane only blank states, an
+    // odd lane only label states -- so the even lanes sum their products as they form them and ONE wave reduction makes the
+    // blank sum; labels equal to the blank id (legal) come from the blank's list like any label's.
+    R zpart = (R)0, epart = (R)0;
     const int L32 = (L + 31) & ~31;   // <= LP; the pads ab[L .. L32) are written as +0 (read by the sums below)
+    const bool blank_lane = (lane & 1) == 0;
     for (int s0 = lane; s0 < L32; s0 += 64 * NB) {
         R av[NB], bv[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int s = s0 + 64 * i;
-            av[i] = (R)0;
-            bv[i] = (R)0;
-            if (s < L) {
-                av[i] = al[s];
-                bv[i] = be[L - 1 - s];
-            }
+            const int s = min(s0 + 64 * i, L - 1);
+            av[i] = al[s];
+            bv[i] = be[L - 1 - s];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -660,6 +668,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<RI> p)
                     if (p.lazy) v = scalbn(av[i], ea) * scalbn(bv[i], eb);
                     else v = av[i] * bv[i];                    // :119
                     ab[s] = v;
+                    epart += blank_lane ? v : (R)0;            // :122-124
                     if (v != (R)0) v = v / (R)y_s[lab_s[s]];   // :125-126 / :130-131
                 } else {
                     ab[s] = (R)0;
@@ -669,51 +678,27 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcGradArgs<RI> p)
         }
     }
     const R Z = wave_sum(zpart);                        // absum[t], :133-136
+    const R gb = wave_sum(epart);
     // LDS writes above are read by other lanes of this wave only
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    // grad[k, t] = sum of ab over the states of label k, in ascending s like the reference (:120-131).  Every
-    // lane used to scan the whole row for its label (L compare-select-adds per lane: 44 k issue cycles per frame
-    // at L = 1601); now the blank lane adds the even states and every other lane walks its host-built list of
-    // states (by_label): the frame costs the blank lane's chain of (L+1)/2 dependent additions.  A label equal
-    // to the blank id (legal) interleaves odd states into the blank sum: that lane then scans.
-    using V4 = typename Vec<R>::v4;
-    const V4* ab4 = reinterpret_cast<const V4*>(ab);
+    // grad[k, t] = sum of ab over the states of label k (:120-131): every lane walks its label's host-built list of
+    // states (by_label), eight entries per trip (entries past the end read the zero pad ab[L]); the blank adds the blank sum
     for (int k = lane; k < p.A; k += 64) {
         R g = (R)0;
         const int j0 = start_s[k], j1 = start_s[k + 1];
-        if (k == p.blank) {
-            if (j1 == j0) {
-                // eight 4-state groups fetched ahead of their 16 dependent additions: the LDS latency (the whole
-                // cost of a one-group-per-trip loop: 21 us per frame) is paid once per 32 states; states
-                // L .. L32-1 hold +0 (phase 1)
-                for (int s4 = 0; s4 < L32 / 4; s4 += 8) {
-                    V4 v[8];
+        for (int j = j0; j < j1; j += 8) {
+            int idx[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = ab4[s4 + i];
+            for (int i = 0; i < 8; ++i) idx[i] = ord_s[min(j + i, j1 - 1)];
+            R a[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        g += v[i].x;
-                        g += v[i].z;
-                    }
-                }
-            } else {
-                for (int s = 0; s < L; ++s)
-                    if (lab_s[s] == k) g += ab[s];
-            }
-        } else {
-            for (int j = j0; j < j1; j += 4) {      // four list entries per trip; entries past the end read the zero pad ab[L]
-                int idx[4];
+            for (int i = 0; i < 8; ++i) a[i] = ab[j + i < j1 ? idx[i] : L];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) idx[i] = ord_s[min(j + i, j1 - 1)];
-                R a[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = ab[j + i < j1 ? idx[i] : L];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) g += a[i];
-            }
+            for (int i = 0; i < 8; ++i) g += a[i];
         }
+        if (k == p.blank) g += gb;
         const R y = (R)y_s[k];
         const R tmp = y * Z;                        // :141
         gr[k] = (RI)(tmp > (R)0 ? y - g / tmp : y); // :142-145 (cast: CUDAMatrix(deltas), brnnet.py:188)
@@ -800,18 +785,28 @@ int launch_ctc_lattice(const CtcLatticeArgs<RI>& a, int B, int K, int W, int laz
     return set_error(SCTC_ERR_ARG, "ctc: label sequence too long (K=%d, W=%d)", K, W);
 }
 
-template <typename R>
-int launch_ctc_grad(const CtcGradArgs<R>& a, int B, int max_T, hipStream_t stream)
+template <typename R, int NB>
+static int launch_ctc_grad_nb(const CtcGradArgs<R>& a, int B, int max_T, hipStream_t stream)
 {
     dim3 grid((max_T + 3) / 4, B), block(256);
     size_t smem = (size_t)a.lp * sizeof(int32_t) + 4 * (size_t)a.lp * sizeof(double) + 4 * (size_t)((a.A + 3) & ~3) * sizeof(R) +
                   ((size_t)a.lp / 2 + a.A + 1) * sizeof(int32_t);
     if (smem > 48 * 1024)
-        SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<R>),
+        SCTC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<R, NB>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(ctc_grad_kernel<R>, grid, block, smem, stream, a);
+    hipLaunchKernelGGL((ctc_grad_kernel<R, NB>), grid, block, smem, stream, a);
     SCTC_HIP_TRY(hipGetLastError());
     return SCTC_OK;
+}
+
+template <typename R>
+int launch_ctc_grad(const CtcGradArgs<R>& a, int B, int max_T, hipStream_t stream)
+{
+    // (short rows: four slices per trip -- the clamped loads of slices beyond the row are not free: 4096 utterances of
+    // 201 states took 7.3 instead of 5.0 ms with sixteen)
+    if (a.lp <= 256) return launch_ctc_grad_nb<R, 4>(a, B, max_T, stream);
+    if (a.lp <= 512) return launch_ctc_grad_nb<R, 8>(a, B, max_T, stream);
+    return launch_ctc_grad_nb<R, 16>(a, B, max_T, stream);
 }
 
 template int launch_ctc_lattice<float>(const CtcLatticeArgs<float>&, int, int, int, int, hipStream_t);
