@@ -787,7 +787,7 @@ def ctc_saturation(out, torch, A, T, U):
 
 def ctc_long_rows(out, torch):
     """roofline_ctc.long_rows: label rows of 1601 lattice states (the cfg-5 shape, T = 8000 / U = 800) at 32 utterances --
-    the wide fused kernel (ctc_fusedw.hip, the default from 12 utterances on) beside the lattice + grad kernels it
+    the wide fused kernel (ctc_fusedw.hip, the default from 18 utterances on) beside the lattice + grad kernels it
     replaces there (SCTC_CTC_WIDE=0), events around the Python entry on device-resident float32 probabilities"""
     import ctc_fast
     A, T, U, B = 33, 8000, 800, 32
@@ -826,7 +826,7 @@ def ctc_long_rows(out, torch):
         "ms": ms["wide"], "achieved": byts / (ms["wide"] * 1e-3) / 1e9, "unit": "GB/s",
         "ms_lattice_grad": ms["lattice_grad"], "achieved_lattice_grad": byts / (ms["lattice_grad"] * 1e-3) / 1e9,
         "max_cost_rel_distance": float(np.max(np.abs(cost["wide"] - cost["lattice_grad"]) / np.abs(cost["lattice_grad"]))),
-        "note": "ctc_fusedw_kernel (meet in the middle on 8 waves per direction, one packed 32-bit row store; default from 12 "
+        "note": "ctc_fusedw_kernel (meet in the middle on 8 waves per direction, one packed 32-bit row store; default from 18 "
                 "utterances on) against ctc_lattice_kernel + ctc_grad_kernel (two float64 lattices; SCTC_CTC_WIDE=0) on the same "
                 "batch; HBM traffic of the two: profiles/r06_ctc_traffic_cfg5.txt (37x against 175x algorithmic at 8 utterances)"}
     del probs

@@ -83,18 +83,16 @@ int ctc_make_plan(int B, int A, int blank, int dtype, const int32_t* T_b, const 
         }
         plan->store_bytes = (dtype == SCTC_F32 && !(sb && atoi(sb) == 64)) ? 4 : 8;
         // Rows of 513..2048 states (round 6): the same schedule on W = 4 / 8 waves per direction (ctc_fusedw.hip), from
-        // SCTC_CTC_WIDE_MIN_B utterances on (default 12; rows of up to 1024 states, four waves: 16).  Below that the lattice
+        // SCTC_CTC_WIDE_MIN_B utterances on (default 18; rows of up to 1024 states, four waves: 24).  Below that the lattice
         // + grad kernels are faster -- their gradient kernel spreads over the CUs the few recursion workgroups leave idle
-        // (cfg-5 shape, T = 8000 / U = 800, 8 utterances: 5.13 against 5.38 ms; 16: 5.72 against 5.45; 128: 15.5 against 6.0;
-        // T = 4000 / U = 511: 8: 1.99 against 2.15, 16: 2.15 / 2.16, 64: 3.06 against 2.25) -- at five times the traffic
-        // and ten times the workspace.
-        // SCTC_CTC_WIDE=0 keeps the lattice + grad kernels throughout, =1 takes the wide kernel whatever the batch and for
-        // shorter rows too (tests); SCTC_CTC_WAVES=8 forces eight waves.
+        // (ms per call, wide / lattice + grad; cfg-5 shape, T = 8000 / U = 800: 8 utterances 5.40 / 4.95, 16: 5.45 / 5.39, 24:
+        // 5.48 / 5.82, 128: 6.0 / 15; T = 4000 / U = 511: 16: 2.17 / 2.05, 24: 2.19 / 2.19, 32: 2.22 / 2.28) -- at five times
+        // the traffic and ten times the workspace.
         const char* wz = getenv("SCTC_CTC_WIDE");
         const char* wb = getenv("SCTC_CTC_WIDE_MIN_B");
         const int wide = wz ? atoi(wz) : -1;
         const bool fused_on = fz ? atoi(fz) != 0 : true;
-        const bool wide_auto = !plan->fused && B >= (wb ? atoi(wb) : (max_L > 1024 ? 12 : 16));
+        const bool wide_auto = !plan->fused && B >= (wb ? atoi(wb) : (max_L > 1024 ? 18 : 24));
         if (!plan->generic && !plan->lazy && A <= 256 && max_L <= 2048 && fused_on && wide != 0 && (wide == 1 || wide_auto)) {
             const char* force = getenv("SCTC_CTC_WAVES");
             W = (max_L > 1024 || (force && atoi(force) == 8)) ? 8 : 4;

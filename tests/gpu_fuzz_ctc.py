@@ -2,7 +2,7 @@
 on the GPU; tests/test_gpu_fuzz.py runs a 20-case subset with a fixed seed in the suite): random alphabet, ragged
 batches, repeats, labels equal to the blank, T < U (empty band), infeasible repeats and
 zero-probability labels (skip), peaked and flat distributions, float32 and float64 I/O,
-one- and four-wave lattices; round 6: rows of up to 2001 states in batches of up to 20 (the wide fused kernel from 12 / 16
+one- and four-wave lattices; round 6: rows of up to 2001 states in batches of up to 20 (the wide fused kernel from 18 / 24
 utterances on; `SCTC_CTC_WIDE=1 python tests/gpu_fuzz_ctc.py ...` soaks it on every shape)."""
 import os
 import sys
@@ -26,7 +26,7 @@ def run(n_cases=60, seed=0):
         B = int(rs.choice([1, 2, 5, 9, 13, 20, 32]))
         blank = int(rs.choice([0, 0, 0, A - 1, A // 2]))
         long_rows = rs.rand() < 0.25          # > 256 lattice states: the four-wave kernel
-        very_long = B <= 20 and rs.rand() < 0.2   # up to 2001 states: four / eight waves, the wide fused kernel from 12 / 16 utterances on
+        very_long = B <= 20 and rs.rand() < 0.2   # up to 2001 states: four / eight waves, the wide fused kernel from 18 / 24 utterances on
         peaked = rs.rand() < 0.5
         f64 = rs.rand() < 0.4
         probs, seqs = [], []

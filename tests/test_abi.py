@@ -97,7 +97,7 @@ def test_argument_errors_need_no_gpu(sctc):
     U[0] = 1500                                                   # 2U+1 > 2048: the generic kernels, no rejection
     T[0] = 1600
     assert L.sctc_ctc_workspace_bytes(ctypes.byref(bt)) >= 2 * 1600 * 3001 * 8
-    # rows of 1025..2048 states (round 6): from 12 utterances on the wide fused kernel -- ONE packed row store, 32-bit on
+    # rows of 1025..2048 states (round 6): from 18 utterances on the wide fused kernel -- ONE packed row store, 32-bit on
     # float32 probabilities -- below that (and with SCTC_CTC_WIDE=0) two float64 lattices of 2048-state rows
     def need(B, dtype, T=1000, Ul=800):
         Tb, Ub = np.full(B, T, dtype=np.int32), np.full(B, Ul, dtype=np.int32)
@@ -105,13 +105,13 @@ def test_argument_errors_need_no_gpu(sctc):
         lo = np.arange(B, dtype=np.int64) * Ul
         b = sctc.CtcBatch(B, 33, 0, dtype, 33, sctc.i32(Tb), sctc.i32(Ub), sctc.i64(o), sctc.i32(lb), sctc.i64(lo), None)
         return L.sctc_ctc_workspace_bytes(ctypes.byref(b))
-    assert need(11, sctc.F32) >= 2 * 11 * 1000 * 2048 * 8
-    assert 12 * 1000 * 1604 * 4 <= need(12, sctc.F32) <= 12 * 1000 * 1604 * 4 + 12 * 40000
-    assert 12 * 1000 * 1604 * 8 <= need(12, sctc.F64) <= 12 * 1000 * 1604 * 8 + 12 * 40000
+    assert need(17, sctc.F32) >= 2 * 17 * 1000 * 2048 * 8
+    assert 18 * 1000 * 1604 * 4 <= need(18, sctc.F32) <= 18 * 1000 * 1604 * 4 + 18 * 40000
+    assert 18 * 1000 * 1604 * 8 <= need(18, sctc.F64) <= 18 * 1000 * 1604 * 8 + 18 * 40000
     for env, lo_bound in (("SCTC_CTC_WIDE", "0"), ("SCTC_CTC_FUSED", "0")):
         os.environ[env] = lo_bound
         try:
-            assert need(12, sctc.F32) >= 2 * 12 * 1000 * 2048 * 8
+            assert need(18, sctc.F32) >= 2 * 18 * 1000 * 2048 * 8
         finally:
             del os.environ[env]
     os.environ["SCTC_CTC_WIDE_MIN_B"] = "1"

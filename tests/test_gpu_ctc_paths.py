@@ -247,7 +247,7 @@ def test_fused_ragged_batch_and_long_lists(mods):
 
 def test_wide_rows_513_to_2048_states(mods):
     """rows of 513..2048 lattice states (BASELINE configs[4]: U = 800 -> 1601) on the wide meet-in-the-middle kernel
-    (the default dispatch takes it from 12 utterances on: single utterances here with
+    (the default dispatch takes it from 18 / 24 utterances on: single utterances here with
     SCTC_CTC_WIDE_MIN_B=1, the batches below as dispatched), against the oracle and against the lattice + grad kernels of rounds 1-5:
     the 512 / 513, 1024 / 1025 and 2047 edges of its shapes (4 waves x 2 and x 4 states, 8 x 4), labels that occur far more often than the 32
     list entries a lane keeps in registers (A = 3), wide alphabets, blank ids at either end, float64 and float32
@@ -443,14 +443,14 @@ def test_32bit_rows_where_the_overlap_is_denormal(mods):
               % (which, err[sound].max(), sound.sum(), err[~sound].max(), (~sound).sum()))
 
 
-def test_cfg5_rows_at_12_utterances_through_the_network(mods):
+def test_cfg5_rows_at_18_utterances_through_the_network(mods):
     """BASELINE configs[4]'s utterance shape (T = 8000, U = 800: 1601 lattice states, 33 symbols) at the smallest
-    minibatch the dispatch gives to the wide fused kernel (12), through NNet.costAndGradBatch on a small network:
+    minibatch the dispatch gives to the wide fused kernel (18), through NNet.costAndGradBatch on a small network:
     costs and gradients against the float64 oracle and against the lattice + grad kernels (SCTC_CTC_WIDE=0)"""
     cf, octc, torch = mods
     from nnets import brnnet
     from oracle import brnn as obrnn
-    D, A, H, NL, TL, B, T, U = 6, 33, 16, 2, 1, 12, 8000, 800
+    D, A, H, NL, TL, B, T, U = 6, 33, 16, 2, 1, 18, 8000, 800
     rs = np.random.RandomState(21)
     datas = [rs.randn(D, T) for _ in range(B)]
     labs = [rs.randint(1, A, size=U).astype(np.int32) for _ in range(B)]
@@ -475,14 +475,14 @@ def test_cfg5_rows_at_12_utterances_through_the_network(mods):
 
 
 def test_wide_rows_through_the_network(mods):
-    """NNet.costAndGradBatch on a minibatch of 17 utterances with label rows of 601..1201 lattice states: the engine's CTC
-    call takes the wide fused kernel (12 utterances or more, 16 for rows of up to 1024 states; packed-minibatch row layout, float32 probabilities, 32-bit
+    """NNet.costAndGradBatch on a minibatch of 25 utterances with label rows of 601..1201 lattice states: the engine's CTC
+    call takes the wide fused kernel (18 utterances or more, 24 for rows of up to 1024 states; packed-minibatch row layout, float32 probabilities, 32-bit
     rows) -- costs and every gradient against the float64 oracle, and against the same minibatch on the lattice + grad
     kernels (SCTC_CTC_WIDE=0)"""
     cf, octc, torch = mods
     from nnets import brnnet
     from oracle import brnn as obrnn
-    D, A, H, NL, TL, B = 8, 20, 32, 2, 1, 17
+    D, A, H, NL, TL, B = 8, 20, 32, 2, 1, 25
     rs = np.random.RandomState(12)
     Us = [int(rs.randint(300, 601)) for _ in range(B)]
     Ts = [int(u + rs.randint(60, 400)) for u in Us]
@@ -496,7 +496,7 @@ def test_wide_rows_through_the_network(mods):
     with np.errstate(all="ignore"):
         cr, gr, sr, _ = obrnn.cost_and_grad_batch(params, datas, labs, TL)
     res = {}
-    for which in ("fused", "lattice"):           # "fused" = default switches: the wide kernel at 17 utterances
+    for which in ("fused", "lattice"):           # "fused" = default switches: the wide kernel at 25 utterances
         with path(which):
             costs, _, skips = net.costAndGradBatch(datas, labs)
         assert not skips.any() and not sr.any()

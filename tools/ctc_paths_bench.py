@@ -21,7 +21,7 @@ import ctc_fast  # noqa: E402
 
 SHAPES = {"cfg3": (32, 1000, 100, 33), "sat": (4096, 1000, 100, 33), "cfg2": (256, 300, 60, 62),
           "cfg5": (8, 8000, 800, 33), "sat1k": (1024, 1000, 100, 33), "cfg4": (32, 2000, 200, 33), "sat4": (2048, 2000, 200, 33),
-          # rows of 1601 states (ctc_fusedw.hip from 12 utterances on): cfg-5's minibatch and larger ones
+          # rows of 1601 states (ctc_fusedw.hip from 18 utterances on): cfg-5's minibatch and larger ones
           "cfg5x32": (32, 8000, 800, 33), "cfg5x128": (128, 8000, 800, 33)}
 PATHS = {"fused": {}, "fused64": {"SCTC_CTC_STORE": "64"}, "fused2w": {"SCTC_CTC_HELPER": "0"},
          "lattice": {"SCTC_CTC_FUSED": "0"},
