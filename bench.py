@@ -438,7 +438,7 @@ def main():
                          "measured": "live, inside the %d timed steps: one hipEvent per kernel group on the "
                                      "compute stream (sctc_brnn_set_profiling(h, 2): recorded asynchronously, "
                                      "resolved after each step, no sync added); phase_ms_exact_timers is one "
-                                     "extra step with synchronising timers; profiles/r05_bench_kernel_stats.csv "
+                                     "extra step with synchronising timers; profiles/r06_bench_kernel_stats.csv "
                                      "is rocprofv3's view of the same command" % args.steps,
                          "launches_per_step": n_gemm_launches,
                          "avg_launch_ms": gemm_ms / n_gemm_launches,
@@ -745,7 +745,7 @@ def ctc_saturation(out, torch, A, T, U):
         "note": "ctc_fused_kernel (two waves per utterance at this batch) on 4096 utterances of T=%d U=%d, float32 "
                 "probabilities resident on the device: `ms` between two events around the C entry sctc_ctc_loss_batch "
                 "(workspace allocation, descriptor build and pinned upload, kernel; the kernel alone: profiles/"
-                "r05_ctc_paths_kernel_stats.csv), `ms_wall` the Python entry ctc_loss_batch with its 4096 label arrays "
+                "r06_ctc_paths_kernel_stats.csv), `ms_wall` the Python entry ctc_loss_batch with its 4096 label arrays "
                 "(rounds 1-4 reported that one: 11.4 ms with the three-kernel path).  The float64 recursion is "
                 "latency/issue-bound, not HBM-bound (DESIGN.md 4.3)" % (T, U)}
     # Which bound it IS on cannot be sampled from inside this process: the SQ counters of the same kernel at the same batch
