@@ -392,7 +392,10 @@ void ctc_fused_kernel(CtcFusedArgs<RI> p)
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const R o = Store<ST>::dec(ob.v[K - 1 - j]);
-            ab[j] = av[j] * (inrow[j] ? o : (R)0);                      // :119
+            // a state beyond the row is exactly 0.0 in av; what the mirrored block holds there (the row before, the pad) is
+            // garbage -- finite whatever its bits in the 32-bit format (the top exponent bit is never set), so no mask there
+            if constexpr (sizeof(ST) == 4) ab[j] = av[j] * o;           // :119
+            else ab[j] = av[j] * (inrow[j] ? o : (R)0);
         }
         R z = (R)0, e = (R)0;
 #pragma unroll
