@@ -575,10 +575,25 @@ void ctc_fused_kernel(CtcFusedArgs<RI> p)
             R zl[PH ? PF : 1], eb[PH ? PF : 1];
             auto post = [&](int i) {
                 if constexpr (PH) {
-                    R rl[KH];
+                    R rl[KH], rb;
+                    if constexpr (NA < KH + 1) {
+                        // 1/y once per SYMBOL (lane k <- 1/y[k]) and gathered per state like y itself, instead of once per
+                        // state: NA reciprocals (8 VALU instructions each) instead of KH + 1 -- the same values bit for bit
+                        R ry[NA];
 #pragma unroll
-                    for (int jj = 0; jj < KH; ++jj) rl[jj] = recip_or_zero(ylv[i][jj]);
-                    products(i, a, ocur[i], recip_or_zero(ybv[i]), rl, zl[i], eb[i]);
+                        for (int q = 0; q < NA; ++q) ry[q] = recip_or_zero((R)ycur[i][q]);
+                        rb = bcast_d(ry, blank);
+#pragma unroll
+                        for (int jj = 0; jj < KH; ++jj) {
+                            const R g = gather_d(ry, lab[jj]);
+                            rl[jj] = valid_lab[jj] ? g : (R)0;
+                        }
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < KH; ++jj) rl[jj] = recip_or_zero(ylv[i][jj]);
+                        rb = recip_or_zero(ybv[i]);
+                    }
+                    products(i, a, ocur[i], rb, rl, zl[i], eb[i]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < K; ++j) enc[i].v[j] = Store<ST>::enc(a[j]);
