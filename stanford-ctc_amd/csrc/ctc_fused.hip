@@ -69,7 +69,10 @@ namespace sctc {
 // per lane, none at 2 -- 116 registers: four waves).
 // Measured (tools/ab_ctc_diet.sh, both libraries in alternation on one box, events around the C entry): 4096 utterances of
 // the cfg-3 shape 4.43-4.52 ms against 4.72-4.86 (-6 %), 1024 utterances 1.27 against 1.23 (+3 %: two waves per SIMD
-// either way, and the dieted code is a little slower) -- so it is its own instantiation, taken from 1537 utterances on.
+// either way, and the dieted code was a little slower) -- so it is its own instantiation.  From 1025 utterances on: two waves
+// per utterance and two / three waves per SIMD mean 1024 / 1536 utterances resident at a time -- 1536 utterances are one round
+// instead of two (1.54 against 1.92 ms), 4096 three instead of four (4.12 / 4.53); up to 1024 the two forms are level since the
+// later trims (1.100 / 1.107 ms; tools/ctc_form_sweep.py).
 template <typename RI, typename ST, int K, int NA, bool HELP>
 struct FusedDiet {
 #ifdef SCTC_FUSED_NO_DIET       // A/B build (tools/build_variant.sh nodiet ctc_fused.hip -DSCTC_FUSED_NO_DIET)
@@ -78,7 +81,7 @@ struct FusedDiet {
     static constexpr bool possible = !HELP && NA == 1 && K <= 4 && sizeof(RI) == 4 && sizeof(ST) == 4;
 #endif
 };
-static constexpr int FUSED_DIET_MIN_B = 1537;
+static constexpr int FUSED_DIET_MIN_B = 1025;
 
 template <typename RI, typename ST, int K, int NA, bool HELP, bool DIET = false>
 __global__ __launch_bounds__(HELP ? 384 : 128) __attribute__((amdgpu_waves_per_eu(DIET ? 3 : 1, 8)))

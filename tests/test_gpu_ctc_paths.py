@@ -34,7 +34,7 @@ def mods():
 class path:
     """context manager: force one CTC path through the environment switches the plan reads per call"""
     ENV = {"fused": {}, "fused64": {"SCTC_CTC_STORE": "64"}, "fused2w": {"SCTC_CTC_HELPER": "0"},
-           # round 6: the two-wave form on its register diet (three waves per SIMD; by default from 1537 utterances on)
+           # round 6: the two-wave form on its register diet (three waves per SIMD; by default from 1025 utterances on)
            "fused2wd": {"SCTC_CTC_HELPER": "0", "SCTC_CTC_DIET_MIN_B": "1"},
            # round 6: the meet-in-the-middle kernel for long rows (ctc_fusedw.hip: 4 / 8 waves per direction; by default for
            # rows of 513..2048 states) forced for every row
