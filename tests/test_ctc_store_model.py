@@ -123,3 +123,60 @@ def test_absum_divides_per_state():
     al, be, lab = both(y, seq)
     assert np.abs(gradient(al, be, y, lab, per_state=True) - g_ref).max() < 1e-12
     assert np.abs(gradient(al, be, y, lab, per_state=False) - g_ref).max() > 1e-5
+
+
+# ---- round 6: the wide fused kernel's bookkeeping (csrc/ctc_fusedw.hip), restated
+
+def wide_block_map(i):
+    """block index -> (utterance, direction), ctc_fusedw_kernel"""
+    return (i >> 4) * 8 + (i & 7), (i >> 3) & 1
+
+
+def test_wide_kernel_pairs_are_eight_apart_on_one_xcd():
+    """the two workgroups of an utterance are blocks i and i + 8: the same XCD (block i runs on XCD i % 8) and at most 8
+    apart in dispatch order, so of the resident workgroups at most 8 can be waiting for a partner that has not been
+    dispatched yet (every other resident workgroup's partner is resident too, finishes, and makes room) -- the argument
+    behind the bounded spin of the kernel's two meetings"""
+    for B in range(1, 70):
+        grid = (B + 7) // 8 * 16
+        seen = {}
+        for i in range(grid):
+            b, d = wide_block_map(i)
+            if b < B:
+                assert (b, d) not in seen
+                seen[(b, d)] = i
+        assert len(seen) == 2 * B
+        for b in range(B):
+            i0, i1 = seen[(b, 0)], seen[(b, 1)]
+            assert i1 - i0 == 8 and i0 % 8 == i1 % 8
+        # dispatch in block order with any capacity > 8: never more than 8 resident blocks whose partner is not resident
+        for cap in (9, 16, 32):
+            resident = set(range(min(cap, grid)))
+            waiting = [i for i in resident if wide_block_map(i)[0] < B
+                       and seen[(wide_block_map(i)[0], 1 - wide_block_map(i)[1])] not in resident]
+            assert len(waiting) <= 8 and len(waiting) < len(resident)
+
+
+def test_wide_kernel_lds_row_layout():
+    """a frame's alpha*beta row in LDS: [NLB blank states][NLB label states], state s of global lane s // K at slot
+    (s // 2) of its half; the lists hold NLB + label position; the pad entry is the slot of state NST - 1, which no label row
+    of the shapes the kernel takes (2U + 1 <= NST - 1) ever reaches -- its product is always +0"""
+    for W, K in ((4, 2), (4, 4), (8, 2), (8, 4)):
+        NT, KH = 64 * W, K // 2
+        NST, NLB = NT * K, NT * K // 2
+        slot = {}
+        for gl in range(NT):
+            for j in range(K):
+                s = K * gl + j
+                base = KH * gl + (j >> 1)
+                slot[s] = base if j % 2 == 0 else NLB + base
+        assert sorted(slot.values()) == list(range(NST))                     # a bijection onto the row
+        assert all(slot[s] == s // 2 + (NLB if s % 2 else 0) for s in range(NST))
+        zrow = NST - 1
+        assert slot[NST - 1] == zrow
+        max_L = NST - 1                                                      # the longest row the shape takes (odd)
+        for U in (1, (max_L - 1) // 2):
+            L = 2 * U + 1
+            assert L <= max_L and NST - 1 >= L                               # state NST - 1 does not exist
+            for pos in range(U):                                             # list entry of label position pos
+                assert NLB + pos == slot[2 * pos + 1] != zrow
